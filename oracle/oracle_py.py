@@ -1,0 +1,187 @@
+"""ctypes loaders for the two CPU checkers — TEST INFRASTRUCTURE ONLY.
+
+* ``Oracle``  — oracle/liboracle_zxc.so, our plain-C restatement (zxc_oracle.c).
+* ``Ref``     — oracle/_ref/libzxc_ref.so, the unmodified reference compiled by
+  oracle/Makefile (present when it was built in the container; travels to the
+  GPU box as a prebuilt file).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module. The product package (zxc_amd) must never import it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "liboracle_zxc.so")
+REF_SO = os.path.join(HERE, "_ref", "libzxc_ref.so")
+
+
+def build(quiet=True):
+    """(Re)build the checkers; building the checker is not using it."""
+    subprocess.run(["make", "-C", HERE, "all"], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+class SeekTable(C.Structure):
+    _fields_ = [("n_blocks", C.c_uint32), ("block_size", C.c_uint32), ("total_decomp", C.c_uint64),
+                ("has_checksum", C.c_int), ("dict_id", C.c_uint32),
+                ("comp_sizes", C.POINTER(C.c_uint32)), ("comp_offsets", C.POINTER(C.c_uint64))]
+
+
+class BlockStats(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("type", "n_sequences", "n_literals", "enc_lit", "enc_tok",
+                                          "enc_off", "lit_bytes", "tok_bytes", "off_bytes",
+                                          "extra_bytes", "n_varints")] + \
+               [("match_bytes", C.c_uint64), ("off_hist", C.c_uint64 * 17), ("overlap_matches", C.c_uint32)]
+
+
+class OracleCtx(C.Structure):
+    _fields_ = [("block_size", C.c_uint32), ("checksum_enabled", C.c_int), ("dict", C.c_void_p),
+                ("dict_size", C.c_size_t), ("dict_huf", C.c_void_p)]
+
+
+class Oracle:
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO):
+            build()
+        L = self.lib = C.CDLL(ORACLE_SO)
+        L.zxo_decompress.restype = C.c_int64
+        L.zxo_decompress.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int,
+                                     C.c_char_p, C.c_size_t, C.c_char_p]
+        L.zxo_decode_block.restype = C.c_int
+        L.zxo_decode_block.argtypes = [C.POINTER(OracleCtx), C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.zxo_seek_table_parse.restype = C.c_int
+        L.zxo_seek_table_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(SeekTable)]
+        L.zxo_seek_table_free.argtypes = [C.POINTER(SeekTable)]
+        L.zxo_seekable_decompress_range.restype = C.c_int64
+        L.zxo_seekable_decompress_range.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(SeekTable),
+                                                    C.c_void_p, C.c_size_t, C.c_uint64, C.c_size_t]
+        L.zxo_checksum32.restype = C.c_uint32
+        L.zxo_checksum32.argtypes = [C.c_char_p, C.c_size_t]
+        L.zxo_block_stats.restype = C.c_int
+        L.zxo_block_stats.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(BlockStats)]
+        L.zxo_hash8.restype = C.c_uint8
+        L.zxo_hash16.restype = C.c_uint16
+        L.zxo_huf_decode_section.restype = C.c_int
+        L.zxo_huf_decode_section.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+
+    def decompress(self, comp: bytes, cap: int, checksum=False, dict_=None, dict_huf=None):
+        """-> (rc, bytes). rc >= 0 is the decoded size, < 0 a zxc_error_t."""
+        out = C.create_string_buffer(max(cap, 1))
+        rc = self.lib.zxo_decompress(comp, len(comp), out if cap else None, cap, int(checksum),
+                                     dict_, len(dict_) if dict_ else 0, dict_huf)
+        return rc, out.raw[:max(rc, 0)]
+
+    def decode_block(self, blk: bytes, block_size: int, cap=None, checksum=False):
+        cap = block_size + 2112 if cap is None else cap
+        ctx = OracleCtx(block_size, int(checksum), None, 0, None)
+        out = C.create_string_buffer(cap + 1)
+        rc = self.lib.zxo_decode_block(C.byref(ctx), blk, len(blk), out, cap)
+        return rc, out.raw[:max(rc, 0)]
+
+    def seek_table(self, comp: bytes):
+        t = SeekTable()
+        if self.lib.zxo_seek_table_parse(comp, len(comp), C.byref(t)) != 0:
+            return None
+        res = dict(n_blocks=t.n_blocks, block_size=t.block_size, total=t.total_decomp,
+                   has_checksum=t.has_checksum, dict_id=t.dict_id,
+                   comp_sizes=[t.comp_sizes[i] for i in range(t.n_blocks)],
+                   comp_offsets=[t.comp_offsets[i] for i in range(t.n_blocks + 1)])
+        self.lib.zxo_seek_table_free(C.byref(t))
+        return res
+
+    def seekable_range(self, comp: bytes, offset: int, length: int):
+        t = SeekTable()
+        if self.lib.zxo_seek_table_parse(comp, len(comp), C.byref(t)) != 0:
+            return None, b""
+        out = C.create_string_buffer(max(length, 1))
+        rc = self.lib.zxo_seekable_decompress_range(comp, len(comp), C.byref(t), out, length, offset, length)
+        self.lib.zxo_seek_table_free(C.byref(t))
+        return rc, out.raw[:max(rc, 0)]
+
+    def block_stats(self, blk: bytes):
+        st = BlockStats()
+        rc = self.lib.zxo_block_stats(blk, len(blk), C.byref(st))
+        return rc, st
+
+
+class CompressOpts(C.Structure):
+    # include/zxc_opts.h:58-78 (reference)
+    _fields_ = [("n_threads", C.c_int), ("level", C.c_int), ("block_size", C.c_size_t),
+                ("checksum_enabled", C.c_int), ("seekable", C.c_int), ("dict", C.c_void_p),
+                ("dict_size", C.c_size_t), ("dict_huf", C.c_void_p), ("progress_cb", C.c_void_p),
+                ("user_data", C.c_void_p)]
+
+
+class DecompressOpts(C.Structure):
+    # include/zxc_opts.h:80-95 (reference)
+    _fields_ = [("n_threads", C.c_int), ("checksum_enabled", C.c_int), ("dict", C.c_void_p),
+                ("dict_size", C.c_size_t), ("dict_huf", C.c_void_p), ("progress_cb", C.c_void_p),
+                ("user_data", C.c_void_p)]
+
+
+def bind_zxc_api(L):
+    """Attach the public zxc C API prototypes (same for the reference .so and
+    for the product libzxc_mi355x.so — that is the drop-in point)."""
+    L.zxc_compress_bound.restype = C.c_uint64
+    L.zxc_compress_bound.argtypes = [C.c_size_t]
+    L.zxc_compress.restype = C.c_int64
+    L.zxc_compress.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(CompressOpts)]
+    L.zxc_decompress.restype = C.c_int64
+    L.zxc_decompress.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(DecompressOpts)]
+    L.zxc_get_decompressed_size.restype = C.c_uint64
+    L.zxc_get_decompressed_size.argtypes = [C.c_char_p, C.c_size_t]
+    L.zxc_seekable_open.restype = C.c_void_p
+    L.zxc_seekable_open.argtypes = [C.c_char_p, C.c_size_t]
+    L.zxc_seekable_free.argtypes = [C.c_void_p]
+    L.zxc_seekable_get_num_blocks.restype = C.c_uint32
+    L.zxc_seekable_get_num_blocks.argtypes = [C.c_void_p]
+    L.zxc_seekable_get_decompressed_size.restype = C.c_uint64
+    L.zxc_seekable_get_decompressed_size.argtypes = [C.c_void_p]
+    L.zxc_seekable_get_block_comp_size.restype = C.c_uint32
+    L.zxc_seekable_get_block_comp_size.argtypes = [C.c_void_p, C.c_uint32]
+    L.zxc_seekable_get_block_decomp_size.restype = C.c_uint32
+    L.zxc_seekable_get_block_decomp_size.argtypes = [C.c_void_p, C.c_uint32]
+    L.zxc_seekable_decompress_range.restype = C.c_int64
+    L.zxc_seekable_decompress_range.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_size_t]
+    L.zxc_seekable_decompress_range_mt.restype = C.c_int64
+    L.zxc_seekable_decompress_range_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64,
+                                                   C.c_size_t, C.c_int]
+    return L
+
+
+class Ref:
+    """The unmodified reference library (oracle/_ref/libzxc_ref.so)."""
+
+    @staticmethod
+    def available():
+        return os.path.exists(REF_SO)
+
+    def __init__(self):
+        self.lib = bind_zxc_api(C.CDLL(REF_SO))
+
+    def compress(self, data: bytes, level=3, block_size=65536, seekable=True, checksum=False) -> bytes:
+        o = CompressOpts(level=level, block_size=block_size, seekable=int(seekable),
+                         checksum_enabled=int(checksum))
+        cap = self.lib.zxc_compress_bound(len(data))
+        dst = C.create_string_buffer(cap)
+        n = self.lib.zxc_compress(data, len(data), dst, cap, C.byref(o))
+        if n < 0:
+            raise RuntimeError(f"reference zxc_compress failed: {n}")
+        return dst.raw[:n]
+
+    def decompress(self, comp: bytes, cap: int, checksum=False):
+        o = DecompressOpts(checksum_enabled=int(checksum))
+        out = C.create_string_buffer(max(cap, 1))
+        rc = self.lib.zxc_decompress(comp, len(comp), out if cap else None, cap, C.byref(o))
+        return rc, out.raw[:max(rc, 0)]
+
+    def seekable_range_mt(self, comp: bytes, offset: int, length: int, threads: int, dst=None):
+        s = self.lib.zxc_seekable_open(comp, len(comp))
+        if not s:
+            return None, b""
+        out = dst if dst is not None else C.create_string_buffer(max(length, 1))
+        rc = self.lib.zxc_seekable_decompress_range_mt(s, out, length, offset, length, threads)
+        self.lib.zxc_seekable_free(s)
+        return rc, (out.raw[:max(rc, 0)] if dst is None else b"")
