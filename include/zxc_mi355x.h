@@ -1,0 +1,69 @@
+/* zxc_mi355x.h — device-resident C-ABI of libzxc_mi355x.so (plain pointers and
+ * sizes; no C++/torch types). This is the boundary the reference's own block loops
+ * would bind to run on an MI355X:
+ *
+ *   zxc_mi355x_decode_blocks_device  replaces the per-block calls to the internal
+ *       zxc_decompress_chunk_wrapper (src/lib/zxc_dispatch.c:279-283, :479-493) made
+ *       by zxc_decompress_frame (:912-1001), the seekable ST loop
+ *       (src/lib/zxc_seekable.c:742-781) and the seekable MT worker (:943-976):
+ *       instead of one 64 KiB block per call on a CPU thread, one launch decodes a
+ *       whole table of independent blocks, one wavefront per block.
+ *   zxc_mi355x_plan_seekable  produces that table from a seekable handle
+ *       (the job planning of src/lib/zxc_seekable.c:1033-1056).
+ *
+ * All d_* arguments are device pointers on the current HIP device. Return values
+ * follow the zxc convention: >= 0 success, < 0 zxc_error_t (zxc_error.h). */
+#ifndef ZXC_MI355X_H
+#define ZXC_MI355X_H
+#include <stddef.h>
+#include <stdint.h>
+#include "zxc_export.h"
+#include "zxc_seekable.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One block to decode (24 bytes, device- and host-visible layout). */
+typedef struct zxc_dev_job {
+    uint64_t comp_off;  /* byte offset of the block's 8-byte header inside d_comp */
+    uint64_t out_off;   /* byte offset inside d_out; MUST be a multiple of 16 */
+    uint32_t comp_size; /* physical block size: header + payload (+ 4-byte checksum trailer) */
+    uint32_t out_len;   /* decoded bytes to keep: block_size, or the archive's tail remainder */
+} zxc_dev_job_t;
+
+/* Number of usable HIP devices (0 when there is none / no driver). */
+ZXC_EXPORT int zxc_mi355x_device_count(void);
+/* Select the device used by the calling thread (hipSetDevice). */
+ZXC_EXPORT int zxc_mi355x_set_device(int device);
+
+/* Device memory helpers so a C caller needs no HIP headers. */
+ZXC_EXPORT void* zxc_mi355x_malloc(size_t bytes);
+ZXC_EXPORT void zxc_mi355x_free(void* d_ptr);
+ZXC_EXPORT int zxc_mi355x_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
+ZXC_EXPORT int zxc_mi355x_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+ZXC_EXPORT int zxc_mi355x_synchronize(void* stream);
+
+/* Fill jobs[0..n_blocks) for blocks [first_block, first_block + n_blocks) of an open
+ * seekable archive. Block i's compressed bytes are expected at
+ * d_comp + (archive_offset(i) - comp_rebase) and its output at
+ * d_out + (i - first_block) * block_size (16-byte aligned by construction).
+ * Pass comp_rebase = 0 when the whole archive was uploaded. Returns n_blocks. */
+ZXC_EXPORT int64_t zxc_mi355x_plan_seekable(const zxc_seekable* s, uint32_t first_block,
+                                            uint32_t n_blocks, uint64_t comp_rebase,
+                                            zxc_dev_job_t* jobs);
+
+/* Decode n_jobs independent blocks, asynchronously on `stream` (a hipStream_t, or
+ * NULL for the default stream). d_status[i] receives block i's decoded size or a
+ * negative zxc_error_t. Requirements: d_out + job.out_off 16-byte aligned; d_out
+ * readable/writable up to round_up(out_off + out_len, 16) + 16. block_size is the
+ * archive's block size (bounds scratch and the per-block output cap
+ * block_size + 2112, like the reference). verify_trailer = 1 means every block
+ * carries and is bound-checked with its 4-byte checksum trailer. */
+ZXC_EXPORT int zxc_mi355x_decode_blocks_device(const void* d_comp, const zxc_dev_job_t* d_jobs,
+                                               uint32_t n_jobs, void* d_out, int32_t* d_status,
+                                               uint32_t block_size, int verify_trailer, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,63 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def manifest():
+    return json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_py
+    if not os.path.exists(oracle_py.ORACLE_SO):
+        oracle_py.build()
+    return oracle_py.Oracle()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    import oracle_py
+    if not oracle_py.Ref.available():
+        pytest.skip("oracle/_ref/libzxc_ref.so not built (needs /root/reference at build time)")
+    return oracle_py.Ref()
+
+
+@pytest.fixture(scope="session")
+def synth_inputs():
+    import make_golden
+    return make_golden.synth_inputs()
+
+
+@pytest.fixture(scope="session")
+def product():
+    import zxc_amd
+    if not os.path.exists(zxc_amd.lib_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+    zxc_amd.lib()
+    return zxc_amd
+
+
+def load_dict(path):
+    """(.zxd) -> (content, 128-byte shared table); layout docs/FORMAT.md §12.4"""
+    raw = open(path, "rb").read()
+    n = raw[6] | (raw[7] << 8)
+    return raw[16:16 + n], raw[16 + n:16 + n + 128]
+
+
+def read(rel):
+    return open(os.path.join(GOLDEN, rel), "rb").read()

@@ -1,0 +1,106 @@
+"""CPU tests of the product library's host side (no GPU compute): it loads, exports every
+symbol include/*.h declares, parses containers like the reference, and fails loudly —
+never falls back to a CPU decoder — when there is no device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, read
+
+
+def test_exports_every_declared_symbol(product):
+    L = product.lib()
+    declared = set()
+    for h in os.listdir(os.path.join(ROOT, "include")):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        declared |= set(re.findall(r"ZXC_EXPORT[^;(]*?\b(zxc_\w+)\s*\(", txt))
+    assert len(declared) >= 25
+    for name in sorted(declared):
+        assert hasattr(L, name), f"include/ declares {name} but libzxc_mi355x.so does not export it"
+
+
+def test_no_oracle_or_reference_linked(product):
+    """The product must not link the checkers."""
+    import subprocess
+    out = subprocess.run(["ldd", product.lib_path()], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "zxc_ref" not in out
+    syms = subprocess.run(["nm", "-D", product.lib_path()], capture_output=True, text=True).stdout
+    assert "zxo_" not in syms
+
+
+def test_opts_layout_and_misc(product):
+    L = product.lib()
+    L.zxc_compress_opts_size.restype = C.c_size_t
+    L.zxc_decompress_opts_size.restype = C.c_size_t
+    assert L.zxc_compress_opts_size() == 64 and L.zxc_decompress_opts_size() == 48  # include/zxc_opts.h:105-111
+    assert product.error_name(-9) == "ZXC_ERROR_BAD_OFFSET"
+    assert product.error_name(-100) == "ZXC_ERROR_GPU_UNAVAILABLE"
+    L.zxc_version_string.restype = C.c_char_p
+    assert L.zxc_version_string() == b"0.13.3"
+    assert (L.zxc_min_level(), L.zxc_default_level(), L.zxc_max_level()) == (1, 3, 7)
+
+
+def test_compress_bound_matches_reference(product, ref):
+    for n in (0, 1, 4095, 4096, 65536, 1 << 20, 211947520):
+        assert product.lib().zxc_compress_bound(n) == ref.lib.zxc_compress_bound(n)
+
+
+def test_container_errors_need_no_gpu(product, manifest):
+    """Header-level rejections happen on the host before any device work, with the
+    reference's pinned codes (conformance/test_conformance.c:228-249)."""
+    host_level = {"all_0xff_garbage", "bad_block_size_field", "bad_checksum_algo", "bad_header_crc", "bad_magic",
+                  "bad_version", "dict_required", "magic_then_zeros", "too_short_4bytes",
+                  "truncated_header_only", "zero_length"}
+    for f, meta in manifest["conformance_invalid"].items():
+        if f[:-4] in host_level:
+            rc, _ = product.decompress(read(f"conformance/invalid/{f}"), 1 << 20, raise_on_error=False)
+            assert rc == meta["expect"], f
+
+
+def test_seekable_handle_matches_oracle(product, oracle, manifest):
+    for name, meta in manifest["synth"].items():
+        comp = read(f"synth/{name}.zxc")
+        if not meta["seekable"]:
+            with pytest.raises(product.ZxcError):
+                product.Seekable(comp)
+            continue
+        s = product.Seekable(comp)
+        t = oracle.seek_table(comp)
+        assert s.num_blocks == t["n_blocks"] and s.decompressed_size == t["total"]
+        assert [s.block_comp_size(i) for i in range(s.num_blocks)] == t["comp_sizes"]
+        jobs = s.plan()
+        assert list(jobs["comp_off"]) == t["comp_offsets"][:-1]
+        assert list(jobs["comp_size"]) == t["comp_sizes"]
+        assert all(int(o) % 16 == 0 for o in jobs["out_off"])
+        assert int(jobs["out_len"].sum()) == t["total"]
+        assert product.get_decompressed_size(comp) == t["total"]
+        s.close()
+
+
+def test_seek_table_writer_matches_reference_bytes(product):
+    # the SEK block of a stored archive must be reproduced byte for byte
+    comp = read("synth/seek_70001_l3_b16k.zxc")
+    s = product.Seekable(comp)
+    n = s.num_blocks
+    sizes = (C.c_uint32 * n)(*[s.block_comp_size(i) for i in range(n)])
+    L = product.lib()
+    L.zxc_seek_table_size.restype = C.c_size_t
+    L.zxc_write_seek_table.restype = C.c_int64
+    tot = L.zxc_seek_table_size(n)
+    buf = C.create_string_buffer(tot)
+    assert L.zxc_write_seek_table(buf, C.c_size_t(tot), sizes, C.c_uint32(n)) == tot
+    assert buf.raw == comp[len(comp) - 12 - tot:len(comp) - 12]
+
+
+@pytest.mark.skipif(os.environ.get("HIP_VISIBLE_DEVICES", "") != "" or os.path.exists("/dev/kfd"),
+                    reason="a GPU is visible")
+def test_fails_loudly_without_gpu(product):
+    comp = read("synth/lorem_100k_l3_b64k.zxc")
+    rc, _ = product.decompress(comp, raise_on_error=False)
+    assert rc == -100  # ZXC_ERROR_GPU_UNAVAILABLE, not a CPU fallback
+    s = product.Seekable(comp)
+    rc, _ = s.decompress_range(0, 1000, raise_on_error=False)
+    assert rc == -100

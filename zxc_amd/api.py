@@ -1,0 +1,157 @@
+"""ctypes binding of libzxc_mi355x.so — same function names as the reference C API
+(include/zxc_buffer.h, include/zxc_seekable.h) plus the device-resident entry points of
+include/zxc_mi355x.h."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# zxc_dev_job_t (include/zxc_mi355x.h)
+JOB_DTYPE = np.dtype([("comp_off", "<u8"), ("out_off", "<u8"), ("comp_size", "<u4"), ("out_len", "<u4")])
+
+
+class ZxcError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = int(code)
+        super().__init__(f"{what}: {error_name(self.code)} ({self.code})")
+
+
+class _DecompressOpts(C.Structure):  # include/zxc_opts.h
+    _fields_ = [("n_threads", C.c_int), ("checksum_enabled", C.c_int), ("dict", C.c_void_p),
+                ("dict_size", C.c_size_t), ("dict_huf", C.c_void_p), ("progress_cb", C.c_void_p),
+                ("user_data", C.c_void_p)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libzxc_mi355x.so")
+
+
+def lib():
+    """The product library. Fails loudly when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise ImportError(f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(p)
+        L.zxc_error_name.restype = C.c_char_p
+        L.zxc_error_name.argtypes = [C.c_int]
+        L.zxc_decompress.restype = C.c_int64
+        L.zxc_decompress.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(_DecompressOpts)]
+        L.zxc_get_decompressed_size.restype = C.c_uint64
+        L.zxc_get_decompressed_size.argtypes = [C.c_char_p, C.c_size_t]
+        L.zxc_compress_bound.restype = C.c_uint64
+        L.zxc_compress_bound.argtypes = [C.c_size_t]
+        L.zxc_seekable_open.restype = C.c_void_p
+        L.zxc_seekable_open.argtypes = [C.c_char_p, C.c_size_t]
+        L.zxc_seekable_free.argtypes = [C.c_void_p]
+        for f in ("zxc_seekable_get_num_blocks",):
+            getattr(L, f).restype = C.c_uint32
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.zxc_seekable_get_decompressed_size.restype = C.c_uint64
+        L.zxc_seekable_get_decompressed_size.argtypes = [C.c_void_p]
+        for f in ("zxc_seekable_get_block_comp_size", "zxc_seekable_get_block_decomp_size"):
+            getattr(L, f).restype = C.c_uint32
+            getattr(L, f).argtypes = [C.c_void_p, C.c_uint32]
+        L.zxc_seekable_decompress_range.restype = C.c_int64
+        L.zxc_seekable_decompress_range.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_size_t]
+        L.zxc_seekable_decompress_range_mt.restype = C.c_int64
+        L.zxc_seekable_decompress_range_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64,
+                                                       C.c_size_t, C.c_int]
+        L.zxc_mi355x_device_count.restype = C.c_int
+        L.zxc_mi355x_set_device.argtypes = [C.c_int]
+        L.zxc_mi355x_plan_seekable.restype = C.c_int64
+        L.zxc_mi355x_plan_seekable.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]
+        L.zxc_mi355x_decode_blocks_device.restype = C.c_int
+        L.zxc_mi355x_decode_blocks_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                                      C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def error_name(code):
+    try:
+        return lib().zxc_error_name(int(code)).decode()
+    except Exception:  # library missing: still give a readable message
+        return f"zxc error {code}"
+
+
+def get_decompressed_size(comp: bytes) -> int:
+    return int(lib().zxc_get_decompressed_size(comp, len(comp)))
+
+
+def decompress(comp: bytes, capacity=None, checksum=False, raise_on_error=True):
+    """zxc_decompress(): whole frame, host buffers in, host buffer out (blocks decode on the GPU)."""
+    cap = get_decompressed_size(comp) if capacity is None else int(capacity)
+    out = C.create_string_buffer(max(cap, 1))
+    o = _DecompressOpts(checksum_enabled=int(checksum))
+    rc = lib().zxc_decompress(comp, len(comp), out if cap else None, cap, C.byref(o))
+    if rc < 0:
+        if raise_on_error:
+            raise ZxcError(rc, "zxc_decompress")
+        return rc, b""
+    return out.raw[:rc] if raise_on_error else (rc, out.raw[:rc])
+
+
+class Seekable:
+    """zxc_seekable handle (include/zxc_seekable.h). Keeps `comp` alive: the C handle borrows it."""
+
+    def __init__(self, comp: bytes):
+        self._comp = comp
+        self._h = lib().zxc_seekable_open(comp, len(comp))
+        if not self._h:
+            raise ZxcError(-6, "zxc_seekable_open (not a seekable archive)")
+
+    def close(self):
+        if self._h:
+            lib().zxc_seekable_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def num_blocks(self):
+        return int(lib().zxc_seekable_get_num_blocks(self._h))
+
+    @property
+    def decompressed_size(self):
+        return int(lib().zxc_seekable_get_decompressed_size(self._h))
+
+    def block_comp_size(self, i):
+        return int(lib().zxc_seekable_get_block_comp_size(self._h, i))
+
+    def block_decomp_size(self, i):
+        return int(lib().zxc_seekable_get_block_decomp_size(self._h, i))
+
+    def decompress_range(self, offset, length, n_threads=None, raise_on_error=True):
+        out = C.create_string_buffer(max(length, 1))
+        if n_threads is None:
+            rc = lib().zxc_seekable_decompress_range(self._h, out, length, offset, length)
+        else:
+            rc = lib().zxc_seekable_decompress_range_mt(self._h, out, length, offset, length, n_threads)
+        if rc < 0:
+            if raise_on_error:
+                raise ZxcError(rc, "zxc_seekable_decompress_range")
+            return rc, b""
+        return out.raw[:rc] if raise_on_error else (rc, out.raw[:rc])
+
+    def plan(self, first=0, count=None, comp_rebase=0):
+        """Job table (numpy structured array) for blocks [first, first+count)."""
+        count = self.num_blocks - first if count is None else count
+        jobs = np.zeros(count, dtype=JOB_DTYPE)
+        rc = lib().zxc_mi355x_plan_seekable(self._h, first, count, comp_rebase, jobs.ctypes.data)
+        if rc < 0:
+            raise ZxcError(rc, "zxc_mi355x_plan_seekable")
+        return jobs
+
+
+def decode_blocks_device(d_comp, d_jobs, n_jobs, d_out, d_status, block_size, verify_trailer=False, stream=0):
+    """zxc_mi355x_decode_blocks_device(): raw device pointers (ints), asynchronous on `stream`."""
+    rc = lib().zxc_mi355x_decode_blocks_device(C.c_void_p(d_comp), C.c_void_p(d_jobs), n_jobs, C.c_void_p(d_out),
+                                               C.c_void_p(d_status), block_size, int(verify_trailer),
+                                               C.c_void_p(stream))
+    if rc < 0:
+        raise ZxcError(rc, "zxc_mi355x_decode_blocks_device")

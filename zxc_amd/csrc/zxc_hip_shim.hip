@@ -1,0 +1,99 @@
+// zxc_hip_shim.hip — the only C <-> HIP crossing of libzxc_mi355x.so.
+// extern "C" entry points declared in include/zxc_mi355x.h; host C code
+// (zxc_host.c) and external callers use plain pointers and sizes only.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/zxc_error.h"
+#include "zxc_dev.h"
+
+extern "C" __global__ void zxc_decode_blocks_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
+                                                    uint8_t* out, int32_t* status, uint32_t block_size,
+                                                    uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride);
+
+// Per-device scratch for expanded literal / token sections: one slot per resident
+// workgroup. Grown on demand, never shrunk; freed at process exit by the driver.
+#define ZXC_MAX_DEVICES 16
+static struct {
+    uint8_t* scratch;
+    size_t bytes;
+    int cus;
+} g_dev[ZXC_MAX_DEVICES];
+
+static int current_device(void) {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= ZXC_MAX_DEVICES) return -1;
+    return d;
+}
+
+extern "C" {
+
+int zxc_mi355x_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int zxc_mi355x_set_device(int device) {
+    return hipSetDevice(device) == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
+}
+
+void* zxc_mi355x_malloc(size_t bytes) {
+    void* p = NULL;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return NULL;
+    return p;
+}
+
+void zxc_mi355x_free(void* d_ptr) {
+    if (d_ptr) (void)hipFree(d_ptr);
+}
+
+int zxc_mi355x_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes) {
+    if (bytes == 0) return ZXC_OK;
+    return hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice) == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
+}
+
+int zxc_mi355x_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes) {
+    if (bytes == 0) return ZXC_OK;
+    return hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
+}
+
+int zxc_mi355x_synchronize(void* stream) {
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
+}
+
+int zxc_mi355x_decode_blocks_device(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32_t n_jobs, void* d_out,
+                                    int32_t* d_status, uint32_t block_size, int verify_trailer, void* stream) {
+    if (n_jobs == 0) return ZXC_OK;
+    if (!d_comp || !d_jobs || !d_out || !d_status) return ZXC_ERROR_NULL_INPUT;
+    if (block_size < (1u << 12) || block_size > (1u << 21) || (block_size & (block_size - 1u))) return ZXC_ERROR_BAD_BLOCK_SIZE;
+    const int dev = current_device();
+    if (dev < 0) return ZXC_ERROR_GPU_UNAVAILABLE;
+    if (g_dev[dev].cus == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        g_dev[dev].cus = cus;
+    }
+    // One wave per block; 8 resident waves per CU is what the 18 KiB LDS footprint
+    // admits, so more workgroups than that only queue. Grid-stride covers the rest.
+    uint32_t grid = (uint32_t)g_dev[dev].cus * 8u;
+    if (grid > n_jobs) grid = n_jobs;
+    const uint32_t stride = (block_size + 64u + 255u) & ~255u;
+    const size_t need = (size_t)grid * stride;
+    if (g_dev[dev].bytes < need) {
+        if (g_dev[dev].scratch) (void)hipFree(g_dev[dev].scratch);
+        g_dev[dev].scratch = NULL;
+        g_dev[dev].bytes = 0;
+        // size for a full grid so later, larger calls do not reallocate
+        const size_t want = (size_t)g_dev[dev].cus * 8u * stride;
+        if (hipMalloc((void**)&g_dev[dev].scratch, want > need ? want : need) != hipSuccess) return ZXC_ERROR_MEMORY;
+        g_dev[dev].bytes = want > need ? want : need;
+    }
+    hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
+                       d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, verify_trailer ? 4u : 0u,
+                       g_dev[dev].scratch, stride);
+    return hipGetLastError() == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
+}
+
+}  // extern "C"

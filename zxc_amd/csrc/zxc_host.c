@@ -1,0 +1,507 @@
+/*
+ * zxc_host.c — host side (plain C) of libzxc_mi355x.so: the reference's public
+ * Buffer and Seekable APIs, re-implemented as *batched block loops* over the HIP
+ * decode kernel. Container logic (headers, CRCs, seek table, footer checks, error
+ * precedence) follows the reference; every block payload is decoded on the GPU —
+ * there is no CPU decoder in this library and no fallback: without a usable HIP
+ * device the calls fail with ZXC_ERROR_GPU_UNAVAILABLE.
+ *
+ *   zxc_decompress                    <- src/lib/zxc_dispatch.c:842-1005
+ *   zxc_get_decompressed_size         <- src/lib/zxc_dispatch.c:1203-1225
+ *   zxc_seekable_open / _open_reader  <- src/lib/zxc_seekable.c:270-554
+ *   zxc_seekable_decompress_range[_mt]<- src/lib/zxc_seekable.c:695-785, :999-1108
+ *   zxc_write_seek_table / _size      <- src/lib/zxc_seekable.c:172-214
+ */
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/zxc.h"
+
+#define MAGIC 0x9CB02EF5u
+#define FORMAT_VERSION 8
+#define BLK_HDR 8
+#define TAIL_PAD 2112u /* ZXC_DECOMPRESS_TAIL_PAD, src/lib/zxc_internal.h:341 */
+enum { BLK_RAW = 0, BLK_GLO = 1, BLK_GHI = 2, BLK_SEK = 254, BLK_EOF = 255 };
+
+static uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+static uint32_t rd32(const uint8_t* p) {
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+static uint64_t rd64(const uint8_t* p) { return (uint64_t)rd32(p) | ((uint64_t)rd32(p + 4) << 32); }
+static void wr32(uint8_t* p, uint32_t v) {
+    p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
+}
+
+/* header check bytes (src/lib/zxc_internal.h:1188-1214): xorshift of the LE words */
+static uint64_t xs_mix(uint64_t h) {
+    h ^= h << 13;
+    h ^= h >> 7;
+    h ^= h << 17;
+    return h;
+}
+static uint8_t hdr_hash8(const uint8_t* p) {
+    const uint64_t h = xs_mix(rd64(p) ^ 0x9E3779B97F4A7C15ull);
+    return (uint8_t)((h >> 32) ^ h);
+}
+static uint16_t hdr_hash16(const uint8_t* p) {
+    const uint64_t h = xs_mix(rd64(p) ^ rd64(p + 8) ^ 0xD2D84A61D2D84A61ull);
+    const uint32_t r = (uint32_t)((h >> 32) ^ h);
+    return (uint16_t)((r >> 16) ^ r);
+}
+
+/* ---------------------------------------------------------------- misc API */
+const char* zxc_error_name(const int code) {
+    switch (code) {
+        case ZXC_OK: return "ZXC_OK";
+        case ZXC_ERROR_MEMORY: return "ZXC_ERROR_MEMORY";
+        case ZXC_ERROR_DST_TOO_SMALL: return "ZXC_ERROR_DST_TOO_SMALL";
+        case ZXC_ERROR_SRC_TOO_SMALL: return "ZXC_ERROR_SRC_TOO_SMALL";
+        case ZXC_ERROR_BAD_MAGIC: return "ZXC_ERROR_BAD_MAGIC";
+        case ZXC_ERROR_BAD_VERSION: return "ZXC_ERROR_BAD_VERSION";
+        case ZXC_ERROR_BAD_HEADER: return "ZXC_ERROR_BAD_HEADER";
+        case ZXC_ERROR_BAD_CHECKSUM: return "ZXC_ERROR_BAD_CHECKSUM";
+        case ZXC_ERROR_CORRUPT_DATA: return "ZXC_ERROR_CORRUPT_DATA";
+        case ZXC_ERROR_BAD_OFFSET: return "ZXC_ERROR_BAD_OFFSET";
+        case ZXC_ERROR_OVERFLOW: return "ZXC_ERROR_OVERFLOW";
+        case ZXC_ERROR_IO: return "ZXC_ERROR_IO";
+        case ZXC_ERROR_NULL_INPUT: return "ZXC_ERROR_NULL_INPUT";
+        case ZXC_ERROR_BAD_BLOCK_TYPE: return "ZXC_ERROR_BAD_BLOCK_TYPE";
+        case ZXC_ERROR_BAD_BLOCK_SIZE: return "ZXC_ERROR_BAD_BLOCK_SIZE";
+        case ZXC_ERROR_DICT_REQUIRED: return "ZXC_ERROR_DICT_REQUIRED";
+        case ZXC_ERROR_DICT_MISMATCH: return "ZXC_ERROR_DICT_MISMATCH";
+        case ZXC_ERROR_DICT_TOO_LARGE: return "ZXC_ERROR_DICT_TOO_LARGE";
+        case ZXC_ERROR_BAD_LEVEL: return "ZXC_ERROR_BAD_LEVEL";
+        case ZXC_ERROR_GPU_UNAVAILABLE: return "ZXC_ERROR_GPU_UNAVAILABLE";
+        case ZXC_ERROR_GPU_UNSUPPORTED: return "ZXC_ERROR_GPU_UNSUPPORTED";
+        default: return "ZXC_UNKNOWN_ERROR";
+    }
+}
+int zxc_min_level(void) { return ZXC_LEVEL_FASTEST; }
+int zxc_max_level(void) { return ZXC_LEVEL_ULTRA; }
+int zxc_default_level(void) { return ZXC_LEVEL_DEFAULT; }
+const char* zxc_version_string(void) { return ZXC_LIB_VERSION_STR; }
+size_t zxc_compress_opts_size(void) { return sizeof(zxc_compress_opts_t); }
+size_t zxc_decompress_opts_size(void) { return sizeof(zxc_decompress_opts_t); }
+
+/* src/lib/zxc_common.c:850-862: header + per-4KiB-block overhead (8 hdr + 4 cksum + 68 fmt)
+ * + input + EOF block + SEK header + 4 B/block + footer */
+uint64_t zxc_compress_bound(const size_t input_size) {
+    if (input_size > (SIZE_MAX - (SIZE_MAX >> 8))) return 0;
+    uint64_t n = ((uint64_t)input_size + ZXC_BLOCK_SIZE_MIN - 1) / ZXC_BLOCK_SIZE_MIN;
+    if (n == 0) n = 1;
+    return ZXC_FILE_HEADER_SIZE + n * (8 + 4 + 68) + (uint64_t)input_size + 8 + 8 + n * 4 + ZXC_FILE_FOOTER_SIZE;
+}
+
+/* ------------------------------------------------------------- containers */
+static int read_file_header(const uint8_t* src, size_t n, uint32_t* block_size, int* has_checksum,
+                            uint32_t* dict_id) {
+    if (n < ZXC_FILE_HEADER_SIZE) return ZXC_ERROR_SRC_TOO_SMALL;
+    if (rd32(src) != MAGIC) return ZXC_ERROR_BAD_MAGIC;
+    if (src[4] != FORMAT_VERSION) return ZXC_ERROR_BAD_VERSION;
+    uint8_t t[16];
+    memcpy(t, src, 16);
+    t[14] = t[15] = 0;
+    if (rd16(src + 14) != hdr_hash16(t) || (src[6] & 0x0F) != 0) return ZXC_ERROR_BAD_HEADER;
+    if (src[5] < ZXC_BLOCK_SIZE_MIN_LOG2 || src[5] > ZXC_BLOCK_SIZE_MAX_LOG2) return ZXC_ERROR_BAD_BLOCK_SIZE;
+    *block_size = 1u << src[5];
+    *has_checksum = (src[6] & 0x80) ? 1 : 0;
+    *dict_id = (src[6] & 0x40) ? rd32(src + 7) : 0;
+    return ZXC_OK;
+}
+
+static int read_block_header(const uint8_t* src, size_t n, uint8_t* type, uint32_t* comp_size) {
+    if (n < BLK_HDR) return ZXC_ERROR_SRC_TOO_SMALL;
+    uint8_t t[8];
+    memcpy(t, src, 8);
+    t[7] = 0;
+    if (src[7] != hdr_hash8(t)) return ZXC_ERROR_BAD_HEADER;
+    *type = src[0];
+    *comp_size = rd32(src + 3);
+    return ZXC_OK;
+}
+
+uint64_t zxc_get_decompressed_size(const void* src, const size_t src_size) {
+    if (!src || src_size < ZXC_FILE_HEADER_SIZE + ZXC_FILE_FOOTER_SIZE) return 0;
+    const uint8_t* p = (const uint8_t*)src;
+    uint32_t bs, did;
+    int cs;
+    if (read_file_header(p, src_size, &bs, &cs, &did) != ZXC_OK) return 0;
+    const uint64_t dsize = rd64(p + src_size - ZXC_FILE_FOOTER_SIZE);
+    /* plausibility cap: each block costs >= 8 compressed bytes (zxc_dispatch.c:1021-1027) */
+    const uint64_t need = dsize / bs + (dsize % bs != 0);
+    return need <= (uint64_t)(src_size / BLK_HDR) ? dsize : 0;
+}
+
+/* ------------------------------------------------------- device round trip */
+/* Decode `n` jobs whose compressed bytes are h_comp[0..comp_bytes) on the host.
+ * Output slot i is out_stride bytes at i*out_stride. Leaves statuses in h_status and,
+ * on success of the launch, the decoded slots in *d_out_ret (caller frees). */
+typedef struct {
+    void* d_comp;
+    void* d_jobs;
+    void* d_out;
+    void* d_status;
+} dev_bufs_t;
+
+static void dev_bufs_free(dev_bufs_t* b) {
+    zxc_mi355x_free(b->d_comp);
+    zxc_mi355x_free(b->d_jobs);
+    zxc_mi355x_free(b->d_out);
+    zxc_mi355x_free(b->d_status);
+    memset(b, 0, sizeof(*b));
+}
+
+static int run_jobs(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_job_t* jobs, uint32_t n,
+                    size_t out_bytes, uint32_t block_size, int verify_trailer, int32_t* h_status,
+                    dev_bufs_t* b) {
+    memset(b, 0, sizeof(*b));
+    if (zxc_mi355x_device_count() <= 0) return ZXC_ERROR_GPU_UNAVAILABLE;
+    /* +64: the kernel's 16-byte literal / extras reads may run past the last block */
+    b->d_comp = zxc_mi355x_malloc(comp_bytes + 64);
+    b->d_jobs = zxc_mi355x_malloc((size_t)n * sizeof(zxc_dev_job_t));
+    b->d_out = zxc_mi355x_malloc(out_bytes + 64);
+    b->d_status = zxc_mi355x_malloc((size_t)n * sizeof(int32_t));
+    int rc = ZXC_ERROR_MEMORY;
+    if (b->d_comp && b->d_jobs && b->d_out && b->d_status) {
+        rc = zxc_mi355x_memcpy_h2d(b->d_comp, h_comp, comp_bytes);
+        if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_h2d(b->d_jobs, jobs, (size_t)n * sizeof(zxc_dev_job_t));
+        if (rc == ZXC_OK)
+            rc = zxc_mi355x_decode_blocks_device(b->d_comp, (const zxc_dev_job_t*)b->d_jobs, n, b->d_out,
+                                                 (int32_t*)b->d_status, block_size, verify_trailer, NULL);
+        if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(NULL);
+        if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(h_status, b->d_status, (size_t)n * sizeof(int32_t));
+    }
+    if (rc != ZXC_OK) dev_bufs_free(b);
+    return rc;
+}
+
+/* ------------------------------------------------------------ zxc_decompress */
+int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, const size_t dst_capacity,
+                       const zxc_decompress_opts_t* opts) {
+    const uint8_t* src = (const uint8_t*)src_v;
+    uint8_t* dst = (uint8_t*)dst_v;
+    if (!src || (!dst && dst_capacity != 0)) return ZXC_ERROR_NULL_INPUT;
+    if (src_size < ZXC_FILE_HEADER_SIZE + ZXC_FILE_FOOTER_SIZE) return ZXC_ERROR_SRC_TOO_SMALL;
+    if (!dst || dst_capacity == 0) { /* empty-frame probe, zxc_dispatch.c:848-853 */
+        if (rd32(src) != MAGIC) return ZXC_ERROR_BAD_MAGIC;
+        return rd64(src + src_size - ZXC_FILE_FOOTER_SIZE) == 0 ? 0 : (int64_t)ZXC_ERROR_DST_TOO_SMALL;
+    }
+    uint32_t block_size, dict_id;
+    int file_ck;
+    const int hrc = read_file_header(src, src_size, &block_size, &file_ck, &dict_id);
+    if (hrc != ZXC_OK) return hrc;
+    const int verify = file_ck && opts && opts->checksum_enabled;
+    const uint8_t* dict = opts ? (const uint8_t*)opts->dict : NULL;
+    const size_t dict_size = (opts && opts->dict) ? opts->dict_size : 0;
+    if (dict_id != 0 && (!dict || dict_size == 0)) return ZXC_ERROR_DICT_REQUIRED;
+    if (dict_id != 0 || dict_size != 0) return ZXC_ERROR_GPU_UNSUPPORTED; /* dictionary prefix: next scope row */
+    if (verify) return ZXC_ERROR_GPU_UNSUPPORTED;                         /* device rapidhash: next scope row */
+
+    /* Pass 1 (host): walk the 8-byte block headers into a job table. A problem found
+     * at block k is only reported if blocks 0..k-1 all decode (the reference stops at
+     * the first failure in stream order). */
+    uint32_t cap_jobs = 64, n = 0;
+    zxc_dev_job_t* jobs = (zxc_dev_job_t*)malloc(cap_jobs * sizeof(*jobs));
+    if (!jobs) return ZXC_ERROR_MEMORY;
+    size_t ip = ZXC_FILE_HEADER_SIZE;
+    int tail_err = 0;     /* error to report after all queued blocks succeed */
+    int saw_eof = 0;
+    while (ip < src_size) {
+        const size_t rem = src_size - ip;
+        uint8_t type;
+        uint32_t csz;
+        if (read_block_header(src + ip, rem, &type, &csz) != ZXC_OK) { tail_err = ZXC_ERROR_BAD_HEADER; break; }
+        if (type == BLK_EOF) {
+            if (csz != 0) tail_err = ZXC_ERROR_BAD_HEADER;
+            saw_eof = 1;
+            break;
+        }
+        if (n == cap_jobs) {
+            cap_jobs *= 2;
+            zxc_dev_job_t* nj = (zxc_dev_job_t*)realloc(jobs, cap_jobs * sizeof(*jobs));
+            if (!nj) { free(jobs); return ZXC_ERROR_MEMORY; }
+            jobs = nj;
+        }
+        jobs[n].comp_off = ip;
+        jobs[n].comp_size = rem > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rem; /* wrapper sees all remaining bytes */
+        jobs[n].out_off = (uint64_t)n * block_size;
+        jobs[n].out_len = block_size;
+        n++;
+        ip += (size_t)BLK_HDR + csz + (file_ck ? 4 : 0);
+    }
+
+    int64_t ret;
+    size_t total = 0;
+    if (n > 0) {
+        int32_t* st = (int32_t*)malloc((size_t)n * sizeof(int32_t));
+        if (!st) { free(jobs); return ZXC_ERROR_MEMORY; }
+        dev_bufs_t b;
+        int rc = run_jobs(src, src_size, jobs, n, (size_t)n * block_size, block_size, 0, st, &b);
+        if (rc != ZXC_OK) { free(st); free(jobs); return rc; }
+        /* sequential semantics: first failing block wins; sizes accumulate in order */
+        int regular = 1;
+        ret = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            if (st[i] < 0) { ret = st[i]; break; }
+            if ((size_t)st[i] > dst_capacity - total) { ret = ZXC_ERROR_DST_TOO_SMALL; break; }
+            if ((uint32_t)st[i] != block_size && i + 1 < n) regular = 0;
+            if ((uint32_t)st[i] > block_size) regular = 0;
+            total += (size_t)st[i];
+        }
+        if (ret == 0 && !regular) {
+            /* Irregular frame (a non-final block shorter/longer than block_size — never
+             * produced by the reference encoder): decoded sizes are a property of the
+             * blocks alone, so re-run with one cap-sized slot per block and gather. */
+            dev_bufs_free(&b);
+            const uint32_t slot = (block_size + TAIL_PAD + 15u) & ~15u;
+            for (uint32_t i = 0; i < n; i++) { jobs[i].out_off = (uint64_t)i * slot; jobs[i].out_len = slot; }
+            rc = run_jobs(src, src_size, jobs, n, (size_t)n * slot, block_size, 0, st, &b);
+            if (rc != ZXC_OK) { free(st); free(jobs); return rc; }
+            size_t op = 0;
+            for (uint32_t i = 0; i < n && rc == ZXC_OK; i++) {
+                rc = zxc_mi355x_memcpy_d2h(dst + op, (const uint8_t*)b.d_out + (size_t)i * slot, (size_t)st[i]);
+                op += (size_t)st[i];
+            }
+            if (rc != ZXC_OK) ret = rc;
+        } else if (ret == 0) {
+            const int crc = zxc_mi355x_memcpy_d2h(dst, b.d_out, total);
+            if (crc != ZXC_OK) ret = crc;
+        }
+        dev_bufs_free(&b);
+        free(st);
+        if (ret < 0) { free(jobs); return ret; }
+    }
+    free(jobs);
+    if (tail_err) return tail_err;
+    if (saw_eof) { /* footer: stored size must equal what was produced (zxc_dispatch.c:936-943) */
+        if (rd64(src + src_size - ZXC_FILE_FOOTER_SIZE) != (uint64_t)total) return ZXC_ERROR_CORRUPT_DATA;
+    }
+    return (int64_t)total;
+}
+
+/* ---------------------------------------------------------------- seekable */
+struct zxc_seekable_s {
+    const uint8_t* src; /* borrowed; NULL in reader mode */
+    uint64_t src_size;
+    zxc_reader_t reader;
+    uint32_t num_blocks;
+    uint32_t block_size;
+    uint64_t total_decomp;
+    int file_has_checksums;
+    uint32_t dict_id;
+    uint32_t* comp_sizes;
+    uint64_t* comp_offsets; /* [num_blocks + 1] */
+};
+
+size_t zxc_seek_table_size(const uint32_t num_blocks) { return BLK_HDR + (size_t)num_blocks * 4; }
+
+int64_t zxc_write_seek_table(uint8_t* dst, const size_t dst_capacity, const uint32_t* comp_sizes,
+                             const uint32_t num_blocks) {
+    if (num_blocks > UINT32_MAX / 4) return ZXC_ERROR_OVERFLOW;
+    const size_t total = zxc_seek_table_size(num_blocks);
+    if (dst_capacity < total) return ZXC_ERROR_DST_TOO_SMALL;
+    if (!dst || !comp_sizes) return ZXC_ERROR_NULL_INPUT;
+    dst[0] = BLK_SEK;
+    dst[1] = dst[2] = 0;
+    wr32(dst + 3, num_blocks * 4);
+    dst[7] = 0;
+    dst[7] = hdr_hash8(dst);
+    for (uint32_t i = 0; i < num_blocks; i++) wr32(dst + BLK_HDR + 4 * (size_t)i, comp_sizes[i]);
+    return (int64_t)total;
+}
+
+void zxc_seekable_free(zxc_seekable* s) {
+    if (!s) return;
+    free(s->comp_sizes);
+    free(s->comp_offsets);
+    free(s);
+}
+
+/* shared by both openers: entries = the SEK payload (num_blocks LE u32) */
+static zxc_seekable* seekable_build(uint32_t block_size, int has_ck, uint32_t dict_id, uint64_t total,
+                                    uint32_t nb, const uint8_t* entries, uint64_t archive_size) {
+    zxc_seekable* s = (zxc_seekable*)calloc(1, sizeof(*s));
+    if (!s) return NULL;
+    s->num_blocks = nb;
+    s->block_size = block_size;
+    s->file_has_checksums = has_ck;
+    s->dict_id = dict_id;
+    s->total_decomp = total;
+    s->src_size = archive_size;
+    s->comp_sizes = (uint32_t*)calloc(nb, sizeof(uint32_t));
+    s->comp_offsets = (uint64_t*)calloc((size_t)nb + 1, sizeof(uint64_t));
+    if (!s->comp_sizes || !s->comp_offsets) { zxc_seekable_free(s); return NULL; }
+    uint64_t acc = ZXC_FILE_HEADER_SIZE;
+    for (uint32_t i = 0; i < nb; i++) {
+        const uint32_t cs = rd32(entries + 4 * (size_t)i);
+        if (cs < BLK_HDR || cs > archive_size) { zxc_seekable_free(s); return NULL; }
+        s->comp_sizes[i] = cs;
+        s->comp_offsets[i] = acc;
+        acc += cs;
+        if (acc > archive_size) { zxc_seekable_free(s); return NULL; }
+    }
+    s->comp_offsets[nb] = acc;
+    return s;
+}
+
+zxc_seekable* zxc_seekable_open(const void* src_v, const size_t n) {
+    const uint8_t* data = (const uint8_t*)src_v;
+    if (!data || n < ZXC_FILE_HEADER_SIZE + 2 * BLK_HDR + ZXC_FILE_FOOTER_SIZE) return NULL;
+    uint32_t bs, did;
+    int ck;
+    if (read_file_header(data, n, &bs, &ck, &did) != ZXC_OK) return NULL;
+    const uint64_t total = rd64(data + n - ZXC_FILE_FOOTER_SIZE);
+    if (total == 0) return NULL;
+    const uint64_t nb = (total + bs - 1) / bs;
+    if (nb > UINT32_MAX) return NULL;
+    const uint64_t entries = nb * 4;
+    if (entries + BLK_HDR + ZXC_FILE_FOOTER_SIZE > n) return NULL;
+    const uint8_t* sek = data + n - ZXC_FILE_FOOTER_SIZE - BLK_HDR - (size_t)entries;
+    uint8_t type;
+    uint32_t csz;
+    if (read_block_header(sek, BLK_HDR + (size_t)entries, &type, &csz) != ZXC_OK) return NULL;
+    if (type != BLK_SEK || csz != (uint32_t)entries) return NULL;
+    zxc_seekable* s = seekable_build(bs, ck, did, total, (uint32_t)nb, sek + BLK_HDR, n);
+    if (!s) return NULL;
+    s->src = data;
+    /* the prefix sum must land on a real EOF block right in front of the SEK block */
+    const uint64_t acc = s->comp_offsets[nb];
+    if (acc != (uint64_t)(sek - data) - BLK_HDR || read_block_header(data + acc, BLK_HDR, &type, &csz) != ZXC_OK ||
+        type != BLK_EOF) {
+        zxc_seekable_free(s);
+        return NULL;
+    }
+    return s;
+}
+
+zxc_seekable* zxc_seekable_open_reader(const zxc_reader_t* r) {
+    if (!r || !r->read_at || r->size == 0) return NULL;
+    if (r->size < ZXC_FILE_HEADER_SIZE + 2 * BLK_HDR + ZXC_FILE_FOOTER_SIZE) return NULL;
+    uint8_t hdr[ZXC_FILE_HEADER_SIZE], foot[ZXC_FILE_FOOTER_SIZE];
+    if (r->read_at(r->ctx, hdr, sizeof hdr, 0) != (int64_t)sizeof hdr) return NULL;
+    uint32_t bs, did;
+    int ck;
+    if (read_file_header(hdr, sizeof hdr, &bs, &ck, &did) != ZXC_OK) return NULL;
+    if (r->read_at(r->ctx, foot, sizeof foot, r->size - sizeof foot) != (int64_t)sizeof foot) return NULL;
+    const uint64_t total = rd64(foot);
+    if (total == 0) return NULL;
+    const uint64_t nb = (total + bs - 1) / bs;
+    if (nb > UINT32_MAX) return NULL;
+    const uint64_t entries = nb * 4;
+    if (entries + BLK_HDR + ZXC_FILE_FOOTER_SIZE > r->size) return NULL;
+    const size_t sek_total = BLK_HDR + (size_t)entries;
+    uint8_t* buf = (uint8_t*)malloc(sek_total);
+    if (!buf) return NULL;
+    zxc_seekable* s = NULL;
+    uint8_t type;
+    uint32_t csz;
+    if (r->read_at(r->ctx, buf, sek_total, r->size - ZXC_FILE_FOOTER_SIZE - sek_total) == (int64_t)sek_total &&
+        read_block_header(buf, sek_total, &type, &csz) == ZXC_OK && type == BLK_SEK && csz == (uint32_t)entries) {
+        s = seekable_build(bs, ck, did, total, (uint32_t)nb, buf + BLK_HDR, r->size);
+        if (s) s->reader = *r;
+    }
+    free(buf);
+    return s;
+}
+
+uint32_t zxc_seekable_get_num_blocks(const zxc_seekable* s) { return s ? s->num_blocks : 0; }
+uint64_t zxc_seekable_get_decompressed_size(const zxc_seekable* s) { return s ? s->total_decomp : 0; }
+uint32_t zxc_seekable_get_block_comp_size(const zxc_seekable* s, const uint32_t i) {
+    return (s && i < s->num_blocks) ? s->comp_sizes[i] : 0;
+}
+uint32_t zxc_seekable_get_block_decomp_size(const zxc_seekable* s, const uint32_t i) {
+    if (!s || i >= s->num_blocks) return 0;
+    const uint64_t rem = s->total_decomp - (uint64_t)i * s->block_size;
+    return rem >= s->block_size ? s->block_size : (uint32_t)rem;
+}
+
+int64_t zxc_mi355x_plan_seekable(const zxc_seekable* s, uint32_t first, uint32_t n, uint64_t comp_rebase,
+                                 zxc_dev_job_t* jobs) {
+    if (!s || !jobs) return ZXC_ERROR_NULL_INPUT;
+    if ((uint64_t)first + n > s->num_blocks) return ZXC_ERROR_SRC_TOO_SMALL;
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t i = first + k;
+        if (s->comp_offsets[i] < comp_rebase) return ZXC_ERROR_CORRUPT_DATA;
+        jobs[k].comp_off = s->comp_offsets[i] - comp_rebase;
+        jobs[k].comp_size = s->comp_sizes[i];
+        jobs[k].out_off = (uint64_t)k * s->block_size;
+        jobs[k].out_len = zxc_seekable_get_block_decomp_size(s, i);
+    }
+    return (int64_t)n;
+}
+
+int64_t zxc_seekable_decompress_range(zxc_seekable* s, void* dst, const size_t dst_capacity, const uint64_t offset,
+                                      const size_t len) {
+    if (len == 0) return 0;
+    if (!s || !dst) return ZXC_ERROR_NULL_INPUT;
+    if (dst_capacity < len) return ZXC_ERROR_DST_TOO_SMALL;
+    if (offset + len > s->total_decomp) return ZXC_ERROR_SRC_TOO_SMALL;
+    if (s->dict_id != 0) return ZXC_ERROR_DICT_REQUIRED; /* no zxc_seekable_set_dict in this build */
+
+    const uint32_t b0 = (uint32_t)(offset / s->block_size);
+    const uint32_t b1 = (uint32_t)((offset + len - 1) / s->block_size);
+    const uint32_t n = b1 - b0 + 1;
+    const uint64_t c0 = s->comp_offsets[b0], c1 = s->comp_offsets[b1 + 1];
+    if (c1 > s->src_size) return ZXC_ERROR_SRC_TOO_SMALL;
+    const size_t comp_bytes = (size_t)(c1 - c0);
+
+    /* compressed span of the covered blocks: borrowed buffer or reader callback */
+    const uint8_t* h_comp;
+    uint8_t* staged = NULL;
+    if (s->src) {
+        h_comp = s->src + c0;
+    } else {
+        staged = (uint8_t*)malloc(comp_bytes ? comp_bytes : 1);
+        if (!staged) return ZXC_ERROR_MEMORY;
+        const int64_t r = s->reader.read_at(s->reader.ctx, staged, comp_bytes, c0);
+        if (r != (int64_t)comp_bytes) { free(staged); return r < 0 ? r : (int64_t)ZXC_ERROR_IO; }
+        h_comp = staged;
+    }
+    zxc_dev_job_t* jobs = (zxc_dev_job_t*)malloc((size_t)n * sizeof(*jobs));
+    int32_t* st = (int32_t*)malloc((size_t)n * sizeof(int32_t));
+    int64_t ret = ZXC_ERROR_MEMORY;
+    if (jobs && st) {
+        zxc_mi355x_plan_seekable(s, b0, n, c0, jobs);
+        /* The reference decodes each block with cap block_size + 2112 and keeps what
+         * the range needs (zxc_seekable.c:758-780): keep whole slots here. */
+        for (uint32_t k = 0; k < n; k++) jobs[k].out_len = s->block_size;
+        dev_bufs_t b;
+        int rc = run_jobs(h_comp, comp_bytes, jobs, n, (size_t)n * s->block_size, s->block_size, 0, st, &b);
+        if (rc != ZXC_OK) {
+            ret = rc;
+        } else {
+            ret = (int64_t)len;
+            /* first failing block in job order wins (zxc_seekable.c:1097-1104) */
+            size_t remaining = len;
+            for (uint32_t k = 0; k < n; k++) {
+                if (st[k] < 0) { ret = st[k]; break; }
+                const uint64_t bstart = (uint64_t)(b0 + k) * s->block_size;
+                const size_t skip = offset > bstart ? (size_t)(offset - bstart) : 0;
+                const size_t want = (s->block_size - skip) < remaining ? (s->block_size - skip) : remaining;
+                /* a block that decodes short of what the range needs from it */
+                const size_t expect = zxc_seekable_get_block_decomp_size(s, b0 + k);
+                const size_t need = (expect - skip) < remaining ? (expect - skip) : remaining;
+                if ((size_t)st[k] < skip + need) { ret = ZXC_ERROR_CORRUPT_DATA; break; }
+                (void)want;
+                remaining -= need;
+            }
+            if (ret >= 0) {
+                const size_t skip0 = (size_t)(offset - (uint64_t)b0 * s->block_size);
+                rc = zxc_mi355x_memcpy_d2h(dst, (const uint8_t*)b.d_out + skip0, len);
+                if (rc != ZXC_OK) ret = rc;
+            }
+            dev_bufs_free(&b);
+        }
+    }
+    free(jobs);
+    free(st);
+    free(staged);
+    return ret;
+}
+
+int64_t zxc_seekable_decompress_range_mt(zxc_seekable* s, void* dst, const size_t dst_capacity, const uint64_t offset,
+                                         const size_t len, int n_threads) {
+    (void)n_threads; /* block-level parallelism is the GPU launch's; CPU threads add nothing */
+    return zxc_seekable_decompress_range(s, dst, dst_capacity, offset, len);
+}
