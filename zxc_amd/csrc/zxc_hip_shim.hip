@@ -10,7 +10,8 @@
 
 extern "C" __global__ void zxc_decode_blocks_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                     uint8_t* out, int32_t* status, uint32_t block_size,
-                                                    uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride);
+                                                    uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride, uint32_t dbg,
+                                                    uint32_t* next_job);
 
 // Per-device scratch for expanded literal / token sections: one slot per resident
 // workgroup. Grown on demand, never shrunk; freed at process exit by the driver.
@@ -19,7 +20,11 @@ static struct {
     uint8_t* scratch;
     size_t bytes;
     int cus;
+    int wg_per_cu;
+    uint32_t* counter; /* work-queue head */
 } g_dev[ZXC_MAX_DEVICES];
+
+static uint32_t g_debug_flags = 0;  // timing ablations, set only by zxc_mi355x__set_debug
 
 static int current_device(void) {
     int d = -1;
@@ -28,6 +33,9 @@ static int current_device(void) {
 }
 
 extern "C" {
+
+/* internal (not in include/): kernel timing ablations for tools/kbench.py */
+__attribute__((visibility("default"))) void zxc_mi355x__set_debug(uint32_t flags) { g_debug_flags = flags; }
 
 int zxc_mi355x_device_count(void) {
     int n = 0;
@@ -75,9 +83,14 @@ int zxc_mi355x_decode_blocks_device(const void* d_comp, const zxc_dev_job_t* d_j
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         g_dev[dev].cus = cus;
     }
-    // One wave per block; 8 resident waves per CU is what the 18 KiB LDS footprint
-    // admits, so more workgroups than that only queue. Grid-stride covers the rest.
-    uint32_t grid = (uint32_t)g_dev[dev].cus * 8u;
+    // One wave per block. Launch exactly as many workgroups as can be resident (LDS- and
+    // register-limited, asked from the runtime once); the kernel grid-strides over the rest.
+    if (g_dev[dev].wg_per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, zxc_decode_blocks_kernel, 64, 0) != hipSuccess || nb <= 0) nb = 8;
+        g_dev[dev].wg_per_cu = nb;
+    }
+    uint32_t grid = (uint32_t)g_dev[dev].cus * (uint32_t)g_dev[dev].wg_per_cu;
     if (grid > n_jobs) grid = n_jobs;
     const uint32_t stride = (block_size + 64u + 255u) & ~255u;
     const size_t need = (size_t)grid * stride;
@@ -86,13 +99,15 @@ int zxc_mi355x_decode_blocks_device(const void* d_comp, const zxc_dev_job_t* d_j
         g_dev[dev].scratch = NULL;
         g_dev[dev].bytes = 0;
         // size for a full grid so later, larger calls do not reallocate
-        const size_t want = (size_t)g_dev[dev].cus * 8u * stride;
+        const size_t want = (size_t)g_dev[dev].cus * (size_t)g_dev[dev].wg_per_cu * stride;
         if (hipMalloc((void**)&g_dev[dev].scratch, want > need ? want : need) != hipSuccess) return ZXC_ERROR_MEMORY;
         g_dev[dev].bytes = want > need ? want : need;
     }
+    if (!g_dev[dev].counter && hipMalloc((void**)&g_dev[dev].counter, 256) != hipSuccess) return ZXC_ERROR_MEMORY;
+    if (hipMemsetAsync(g_dev[dev].counter, 0, 4, (hipStream_t)stream) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
     hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
                        d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, verify_trailer ? 4u : 0u,
-                       g_dev[dev].scratch, stride);
+                       g_dev[dev].scratch, stride, g_debug_flags, g_dev[dev].counter);
     return hipGetLastError() == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
 }
 
