@@ -68,17 +68,14 @@ def gen_text(n: int, rng, n_words=50000, zipf_a=1.07, phrase_frac=0.30) -> np.nd
     n_phr = 6000
     phr_len = rng.integers(2, 7, n_phr)
     phr_start = rng.integers(0, n_tok - 8, n_phr)
-    pos = 0
-    use = rng.random(n_tok) < (phrase_frac / 4.0)
-    sel = np.flatnonzero(use)
-    pid = np.searchsorted(np.cumsum(1.0 / np.arange(1, n_phr + 1)) / np.sum(1.0 / np.arange(1, n_phr + 1)),
-                          rng.random(sel.size)).clip(0, n_phr - 1)
+    sel = np.flatnonzero(rng.random(n_tok) < (phrase_frac / 4.0))
+    pp = 1.0 / np.arange(1, n_phr + 1)
+    pid = np.searchsorted(np.cumsum(pp / pp.sum()), rng.random(sel.size)).clip(0, n_phr - 1)
     for k in range(6):  # overwrite w[sel+k] with the phrase's k-th word where the phrase is long enough
         m = phr_len[pid] > k
         tgt = sel[m] + k
         ok = tgt < n_tok
         w[tgt[ok]] = w[(phr_start[pid[m]] + k)[ok]]
-    del pos
     out = _concat_by_index(pool, starts[w], lens[w])
     return out[:n] if out.size >= n else np.resize(out, n)
 
@@ -95,13 +92,6 @@ def gen_source(n: int, rng) -> np.ndarray:
     t = rng.integers(0, len(templates), n_lines)
     p = 1.0 / np.arange(1, 2001) ** 1.1
     ident = np.searchsorted(np.cumsum(p / p.sum()), rng.random(n_lines)).clip(0, 1999)
-    parts = []
-    for line in range(0, n_lines, 1 << 16):  # chunked python loop over templates only
-        tt = t[line:line + (1 << 16)]
-        ii = ident[line:line + (1 << 16)]
-        for k, tpl in enumerate(templates):
-            pass
-        break
     # vectorised assembly: pre/post halves of each template around the identifier
     pre = [tp.split(b"%s")[0] for tp in templates]
     post = [tp.split(b"%s")[1] if b"%s" in tp else b"" for tp in templates]
@@ -134,28 +124,42 @@ def gen_records(n: int, rng, rec=128) -> np.ndarray:
 
 
 def gen_exe(n: int, rng) -> np.ndarray:
-    """Executable-like: skewed opcode histogram with ~35 % repeated 4-64 B fragments."""
-    hist = rng.dirichlet(np.full(256, 0.08))
-    base = rng.choice(256, n, p=hist).astype(np.uint8)
-    n_frag = n // 48
-    flen = rng.integers(4, 65, n_frag)
-    dst = rng.integers(70000, max(n - 70, 70001), n_frag)
-    dist = (2.0 ** rng.uniform(3, 16, n_frag)).astype(np.int64)
-    take = rng.random(n_frag) < 0.75
-    for i in np.flatnonzero(take):  # sequential: later copies may copy earlier copies
-        d = int(dst[i]); L = int(flen[i]); s = d - int(dist[i])
-        if s >= 0 and d + L <= n:
-            base[d:d + L] = base[s:s + L]
-    return base
+    """Executable-like (mozilla/ooffice class): instruction idioms drawn Zipf-style from a pool
+    of 6000 short fragments, interleaved with skewed "immediate" bytes."""
+    n_frag = 6000
+    flen = rng.integers(3, 14, n_frag)
+    hist = rng.dirichlet(np.full(256, 0.25))
+    pool = rng.choice(256, int(flen.sum()), p=hist).astype(np.uint8)
+    fstart = np.cumsum(flen) - flen
+    imm_len = 4096
+    imm = rng.integers(0, 256, imm_len, dtype=np.uint8)
+    pool = np.concatenate([pool, imm])
+    k = int(n / 6.0) + 64
+    p = 1.0 / np.arange(1, n_frag + 1) ** 0.95
+    f = np.searchsorted(np.cumsum(p / p.sum()), rng.random(k)).clip(0, n_frag - 1)
+    ilen = rng.choice(np.array([0, 0, 1, 1, 2, 4]), k)                  # immediate bytes after each fragment
+    istart = int(flen.sum()) + rng.integers(0, imm_len - 8, k)
+    seg_s = np.stack([fstart[f], istart], axis=1).reshape(-1)
+    seg_l = np.stack([flen[f], ilen], axis=1).reshape(-1)
+    out = _concat_by_index(pool, seg_s, seg_l)
+    # fresh random immediates so they do not all match the small pool
+    m = rng.random(out.size) < 0.06
+    out = out.copy()
+    out[m] = rng.integers(0, 256, int(m.sum()), dtype=np.uint8)
+    return out[:n] if out.size >= n else np.resize(out, n)
 
 
-def gen_image16(n: int, rng, width=1024) -> np.ndarray:
-    """16-bit medical-image-like: smooth 2-D field + small noise, little-endian u16."""
+def gen_image16(n: int, rng, width=512) -> np.ndarray:
+    """16-bit medical-image-like (mr / x-ray class): smooth field, few grey levels per region,
+    little-endian u16; background rows repeat."""
     px = n // 2 + 1
     rows = px // width + 1
-    y = np.cumsum(rng.normal(0, 3.0, rows))[:, None]
-    x = np.cumsum(rng.normal(0, 3.0, width))[None, :]
-    img = 2000 + 40 * np.sin(y / 30.0) * np.cos(x / 40.0) * 20 + y + x + rng.normal(0, 2.0, (rows, width))
+    y = np.cumsum(rng.normal(0, 1.0, rows))[:, None]
+    x = np.cumsum(rng.normal(0, 1.0, width))[None, :]
+    img = 900 + 6 * (y + x) + 300 * np.sin(y / 25.0) * np.cos(x / 33.0)
+    img = (np.round(img / 8.0) * 8.0) + rng.integers(0, 2, (rows, width)) * 8
+    bg = (np.abs(np.sin(y / 40.0)) < 0.25) & (np.abs(x) > -1)           # dark background bands
+    img = np.where(bg, 16.0 + rng.integers(0, 2, (rows, width)) * 8, img)
     img = np.clip(img, 0, 4095).astype("<u2")
     return img.view(np.uint8).reshape(-1)[:n]
 
@@ -168,7 +172,10 @@ def gen_catalogue(n: int, rng, rec=28) -> np.ndarray:
         v = np.cumsum(rng.normal(0, 1e-3, rows)).astype("<f4")
         a[:, c:c + 4] = v.view(np.uint8).reshape(rows, 4)
     a[:, 20:24] = np.arange(rows, dtype="<u4").view(np.uint8).reshape(rows, 4)
-    a[:, 24:28] = rng.integers(0, 256, (rows, 4), dtype=np.uint8)
+    cls = rng.integers(0, 256, (40, 4), dtype=np.uint8)               # spectral-class-like column
+    a[:, 24:28] = cls[rng.integers(0, 40, rows)]
+    a[:, 0:2] = 0
+    a[:, 4:6] = 0
     return a.reshape(-1)[:n]
 
 

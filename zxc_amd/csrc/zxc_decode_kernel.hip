@@ -37,7 +37,8 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 #define RING_WORDS (RING_BYTES / 4u)
 #define RING_WMASK (RING_WORDS - 1u)
 #define TILE_MAX (RING_BYTES / 2u)   // a batch never spans more output than this (half the ring)
-#define SHORT_MAX 32u    // matches up to this long are copied lane-per-sequence
+#define SHORT_MAX 32u    // one register step of a lane-per-sequence copy
+#define MED_MAX 128u     // matches up to this long are copied lane-per-sequence (4 steps)
 
 // zxc_error_t values (reference include/zxc_error.h:38-74)
 #define E_DST_TOO_SMALL (-2)
@@ -487,18 +488,24 @@ __device__ int run_sequences(const LzStreams& S, uint8_t* __restrict__ dst, uint
             const uint32_t tile_end = __shfl(E, (int)(k - 1u));
             const uint32_t ring_lo = tile_end > RING_BYTES ? tile_end - RING_BYTES : 0u;
 
-            // ---- literals: <= 16 B per sequence straight from registers, longer runs by the whole wave
+            // ---- literals: lane-per-sequence, 16 B register steps (up to 64 B), longer runs by the whole wave
             {
-                const bool lshort = mine && ll != 0u && ll <= 16u && !(S.dbg & DBG_NO_LIT);
-                v4u lv = {0, 0, 0, 0};
-                uint32_t ltail = 0;
-                if (lshort) {
-                    lv = ld128(S.lit + lst);
-                    ltail = ld32(S.lit + lst + put_tail_index(est, ll));
+                const bool lshort = mine && ll != 0u && ll <= 64u && !(S.dbg & DBG_NO_LIT);
+#pragma unroll 1
+                for (uint32_t so = 0; so < 64u; so += 16u) {
+                    const bool act = lshort && so < ll;
+                    if (__ballot(act) == 0ull) break;
+                    const uint32_t n = (ll - so < 16u) ? ll - so : 16u;
+                    v4u lv = {0, 0, 0, 0};
+                    uint32_t ltail = 0;
+                    if (act) {
+                        lv = ld128(S.lit + lst + so);
+                        ltail = ld32(S.lit + lst + so + put_tail_index(est + so, n));
+                    }
+                    const uint32_t lw[4] = {lv.x, lv.y, lv.z, lv.w};
+                    ring_put<4>(L, est + so, n, lw, ltail, act);
                 }
-                const uint32_t lw[4] = {lv.x, lv.y, lv.z, lv.w};
-                ring_put<4>(L, est, ll, lw, ltail, lshort);
-                uint64_t lm = __ballot(mine && ll > 16u);
+                uint64_t lm = __ballot(mine && ll > 64u);
                 while (lm) {
                     const int j = __ffsll((unsigned long long)lm) - 1;
                     lm &= lm - 1ull;
@@ -522,46 +529,57 @@ __device__ int run_sequences(const LzStreams& S, uint8_t* __restrict__ dst, uint
                 if (pending && qb > p && jbp > ja && !(S.dbg & DBG_NO_DEPS))
                     need = ((jbp >= 64u) ? ~0ull : ((1ull << jbp) - 1ull)) & ~((1ull << ja) - 1ull);
             }
-            const bool is_long = ml > SHORT_MAX;
             const bool overlap = off < ml;
+            // lane-per-sequence in 32-byte steps works whenever a step's source is complete before
+            // the step runs: no overlap at all, or a period of at least one step.
+            const bool stepable = ml <= MED_MAX && (!overlap || off >= SHORT_MAX);
+            const bool bytewise = overlap && off < SHORT_MAX && ml <= SHORT_MAX;
+            const bool is_long = !stepable && !bytewise;
             bool far_waited = false;
             for (uint32_t round = 0;; round++) {
                 const uint64_t dm = __ballot(!pending);
                 if (dm == ~0ull) break;
                 if (round > 70u) return ZXC_DEV_E_INTERNAL;  // cannot happen: the lowest pending lane is always ready
                 const bool can = pending && ((dm & need) == need);
-                // short, non-overlapping: 32 source bytes into registers (ring, or L2 when the
-                // source has left the ring), then one exact-length put
-                const bool sa = can && !is_long && !overlap && !(S.dbg & DBG_NO_SHORT);
+                // lane-per-sequence copy: 32 source bytes into registers (ring, or L2 when the source
+                // has left the ring), one exact-length put; up to MED_MAX bytes in 4 steps
+                const bool sa = can && stepable && !(S.dbg & DBG_NO_SHORT);
                 if (__ballot(sa)) {
-                    const bool isfar = sa && qa < ring_lo;
-                    const uint32_t ts = put_tail_index(M, ml);
-                    v4u s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
-                    uint32_t tw = 0;
-                    if (__ballot(isfar)) {
-                        if (!far_waited) { __builtin_amdgcn_s_waitcnt(0); far_waited = true; }
-                        if (isfar) {
-                            s0 = far_rd128(O, qa);
-                            if (ml > 16u) s1 = far_rd128(O, qa + 16u);
+#pragma unroll 1
+                    for (uint32_t so = 0; so < MED_MAX; so += SHORT_MAX) {
+                        const bool act = sa && so < ml;
+                        if (__ballot(act) == 0ull) break;
+                        const uint32_t n = (ml - so < SHORT_MAX) ? ml - so : SHORT_MAX;
+                        const uint32_t q = qa + so, d = M + so;
+                        const bool isfar = act && q < ring_lo;
+                        const uint32_t ts = put_tail_index(d, n);
+                        v4u s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+                        if (__ballot(isfar)) {
+                            if (!far_waited) { __builtin_amdgcn_s_waitcnt(0); far_waited = true; }
+                            if (isfar) {
+                                s0 = far_rd128(O, q);
+                                if (n > 16u) s1 = far_rd128(O, q + 16u);
+                            }
                         }
-                    }
-                    if (sa && !isfar) {
-                        s0 = ring_rd128(L, qa);
-                        if (ml > 16u) s1 = ring_rd128(L, qa + 16u);
-                    }
-                    {   // the 4 bytes at source index ts, out of the registers just loaded
-                        const uint32_t sw[9] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, 0u};
-                        uint32_t lo = 0, hi = 0;
+                        if (act && !isfar) {
+                            s0 = ring_rd128(L, q);
+                            if (n > 16u) s1 = ring_rd128(L, q + 16u);
+                        }
+                        uint32_t tw;
+                        {   // the 4 bytes at source index ts, out of the registers just loaded
+                            const uint32_t sw[9] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, 0u};
+                            uint32_t lo = 0, hi = 0;
 #pragma unroll
-                        for (int j = 0; j < 8; j++)
-                            if ((ts >> 2) == (uint32_t)j) { lo = sw[j]; hi = sw[j + 1]; }
-                        tw = __builtin_amdgcn_alignbyte(hi, lo, ts & 3u);
+                            for (int j = 0; j < 8; j++)
+                                if ((ts >> 2) == (uint32_t)j) { lo = sw[j]; hi = sw[j + 1]; }
+                            tw = __builtin_amdgcn_alignbyte(hi, lo, ts & 3u);
+                        }
+                        const uint32_t sw8[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                        ring_put<8>(L, d, n, sw8, tw, act);
                     }
-                    const uint32_t sw8[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-                    ring_put<8>(L, M, ml, sw8, tw, sa);
                 }
-                // short, overlapping (off < ml <= 32): byte loop over the period [M-off, M)
-                const bool sb = can && !is_long && overlap && !(S.dbg & DBG_NO_SHORT);
+                // short period (off < 32 and off < ml <= 32): byte loop over the period [M-off, M)
+                const bool sb = can && bytewise && !(S.dbg & DBG_NO_SHORT);
                 if (__ballot(sb)) {
                     uint32_t r = 0;
 #pragma unroll 1
@@ -783,7 +801,16 @@ zxc_decode_blocks_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* 
                 else {
                     const uint32_t n = comp_sz < out_len ? comp_sz : out_len;
                     const uint8_t* s8 = src + 8;
-                    for (uint32_t i = 16u * lane; i + 16u <= n; i += 1024u) *(v4u*)(dst + i) = ld128(s8 + i);
+                    uint32_t i = 16u * lane;
+                    for (; i + 3072u + 16u <= n; i += 4096u) {  // 4 x 1 KiB in flight per wave
+                        const v4u a0 = ld128(s8 + i), a1 = ld128(s8 + i + 1024u), a2 = ld128(s8 + i + 2048u),
+                                  a3 = ld128(s8 + i + 3072u);
+                        *(v4u*)(dst + i) = a0;
+                        *(v4u*)(dst + i + 1024u) = a1;
+                        *(v4u*)(dst + i + 2048u) = a2;
+                        *(v4u*)(dst + i + 3072u) = a3;
+                    }
+                    for (; i + 16u <= n; i += 1024u) *(v4u*)(dst + i) = ld128(s8 + i);
                     const uint32_t tail = n & ~15u;
                     if (tail + (uint32_t)lane < n) dst[tail + lane] = s8[tail + lane];
                     rc = (int)comp_sz;
