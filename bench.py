@@ -45,6 +45,19 @@ def build_workload(base_bytes, level, block_size, seed=0):
     return data, comp, dict(gen_s=round(t1 - t0, 2), compress_s=round(t2 - t1, 2), encoder="reference _ref")
 
 
+def pmc_traffic(args, replicas):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/<round>_summary.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command). Only valid for
+    the configuration the profile was taken on; otherwise null."""
+    try:
+        summ = json.load(open(os.path.join(ROOT, "profiles", "r1_summary.json")))
+        if (args.base_mib, replicas, args.level, args.block_size) == (64, 32, 3, 65536):
+            return summ["hbm_traffic_bytes_per_launch"]["total"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(comp, total, budget_s=12.0):
     """The reference's own parallel seekable decode on this box's host cores (bounded sample)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -179,7 +192,7 @@ def main():
                        "ratio": round(out_bytes / (algo_bytes - out_bytes), 3), "parallelism": f"block-range x{world}, no collectives",
                        "prep": prep},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, R),
                          "kernel": "zxc_decode_blocks_kernel", "avg_launch_ms": round(avg_kernel_s * 1e3, 4),
                          "algorithmic_bytes_per_launch": algo_bytes},
             "bit_exact": True,
