@@ -1,0 +1,87 @@
+"""Multi-GPU path on CPU: 2 gloo ranks partition a real seek table exactly like bench.py /
+the device API would (contiguous block range per rank, no data-path collective), decode their
+ranges with the checker, and only the timing/accounting reduction crosses ranks."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zxc_amd import shard
+    import zxc_amd
+    import oracle_py
+    comp = open(os.path.join(GOLDEN, "synth", "text_200k_l3_b4k.zxc"), "rb").read()
+    s = zxc_amd.Seekable(comp)
+    n = s.num_blocks
+    lo, hi = shard.block_range(rank, world, n)
+    jobs = s.plan(lo, hi - lo, comp_rebase=0)
+    # the rank's slice is self-contained: decode it with the oracle block by block
+    o = oracle_py.Oracle()
+    out = bytearray()
+    for j in jobs:
+        rc, b = o.decode_block(comp[int(j["comp_off"]):int(j["comp_off"]) + int(j["comp_size"])], 4096)
+        assert rc == int(j["out_len"])
+        out += b
+    mine = torch.tensor([hi - lo, len(out), int(jobs["comp_size"].sum())], dtype=torch.int64)
+    dist.all_reduce(mine, op=dist.ReduceOp.SUM)          # accounting only
+    t = torch.tensor([0.25 * (rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)              # bench.py's max-over-ranks time
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (lo, hi, bytes(out)))
+    if rank == 0:
+        q.put((n, s.decompressed_size, mine.tolist(), float(t.item()), gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_block_range_partition(synth_inputs, manifest):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    n, total, sums, tmax, gathered = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sums[0] == n and sums[1] == total
+    assert tmax == 0.5
+    gathered.sort()
+    assert gathered[0][0] == 0 and gathered[-1][1] == n
+    assert all(gathered[i][1] == gathered[i + 1][0] for i in range(world - 1))  # disjoint, contiguous cover
+    data = synth_inputs[manifest["synth"]["text_200k_l3_b4k"]["input"]]
+    assert b"".join(g[2] for g in gathered) == data
+
+
+def test_range_helpers():
+    from zxc_amd import shard
+    for n in (0, 1, 7, 8, 1000003):
+        for w in (1, 2, 4, 8):
+            r = [shard.block_range(g, w, n) for g in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+    costs = [1, 100, 1, 1, 100, 1, 1, 1]
+    rr = shard.byte_balanced_ranges(2, costs)
+    assert rr[0][0] == 0 and rr[-1][1] == len(costs) and rr[0][1] == rr[1][0]
