@@ -36,8 +36,6 @@ def test_conformance_valid(gpu, oracle, name):
     if name.startswith("dict_"):
         assert rc in (-15, UNSUPPORTED)  # dictionary archives: next scope row, must not decode silently
         return
-    if rc == UNSUPPORTED:
-        pytest.xfail("PivCo section (level 6/7) not on device yet")
     assert rc == len(exp) and out == exp
 
 
@@ -55,7 +53,8 @@ def test_format_golden(gpu, manifest):
         if meta["ref_rc"] < 0:
             continue
         rc, out = gpu.decompress(read(f"format/{f}"), meta["decoded_size"], raise_on_error=False)
-        if rc == UNSUPPORTED:
+        if f in ("09_block_dict.zxc", "12_glo_huffman_dict.zxc"):
+            assert rc in (-15, UNSUPPORTED)  # dictionary archives: next scope row
             continue
         assert rc == meta["decoded_size"], f
         assert hashlib.sha256(out).hexdigest() == meta["decoded_sha256"], f
@@ -69,18 +68,16 @@ def test_synth_archives_all_levels(gpu, manifest, synth_inputs):
         comp = read(f"synth/{name}.zxc")
         data = synth_inputs[meta["input"]]
         rc, out = gpu.decompress(comp, len(data), raise_on_error=False)
-        if rc == UNSUPPORTED and meta["level"] >= 6:
-            continue
         assert rc == len(data), (name, rc)
         assert out == data, name
         seen_ok += 1
-    assert seen_ok >= 12
+    assert seen_ok >= 14
 
 
 def test_seekable_ranges(gpu, manifest, synth_inputs):
     rng = random.Random(3)
     for name, meta in manifest["synth"].items():
-        if not meta["seekable"] or meta["level"] >= 6:
+        if not meta["seekable"]:
             continue
         comp = read(f"synth/{name}.zxc")
         data = synth_inputs[meta["input"]]
@@ -99,7 +96,8 @@ def test_seekable_ranges(gpu, manifest, synth_inputs):
 def test_mutated_blocks_match_oracle_exactly(gpu, oracle, manifest):
     """Per-block differential fuzz: same accept/reject decision, same error code, same bytes."""
     rng = random.Random(11)
-    for name in ("mixed_384k_l3_b64k", "mixed_384k_l1_b64k", "text_200k_l3_b4k", "period300_150k_l5_b64k"):
+    for name in ("mixed_384k_l3_b64k", "mixed_384k_l1_b64k", "text_200k_l3_b4k", "period300_150k_l5_b64k",
+                 "mixed_384k_l7_b64k", "mixed_384k_l6_b64k"):
         comp = read(f"synth/{name}.zxc")
         size = manifest["synth"][name]["size"]
         for _ in range(40):
@@ -118,7 +116,7 @@ def test_large_corpus_roundtrip_properties(gpu, ref):
     the GPU, sha256 must match the generator's bytes (size-independent round-trip property)."""
     from zxc_amd import corpus
     data = corpus.synth_silesia(32 << 20, seed=0)
-    for level in (1, 3, 5):
+    for level in (1, 3, 5, 6):
         comp = ref.compress(data, level, 65536, True, False)
         s = gpu.Seekable(comp)
         out = s.decompress_range(0, len(data))

@@ -350,6 +350,8 @@ __device__ uint32_t parse_varints(const uint8_t* ext, uint32_t ext_size, uint32_
     return kbad;
 }
 
+#include "zxc_pivco.inc"
+
 // ------------------------------------------------------------------ block decode
 struct LzStreams {
     const uint8_t* lit;   // literal bytes (payload, or expanded scratch)
@@ -734,8 +736,14 @@ __device__ int decode_lz_block(const uint8_t* data, uint32_t comp_sz, bool ghi, 
         if (lit_comp > avail) return E_CORRUPT;
         if (S.n_lit != 0u) {
             if (S.n_lit > cap) return E_DST_TOO_SMALL;
-            if (enc_lit == 3u) return E_DICT_REQUIRED;
-            return ZXC_DEV_E_UNSUPPORTED;  // PivCo literal section: not in this kernel yet
+            if (enc_lit == 3u) return E_DICT_REQUIRED;  // shared-table sections need a dictionary (next scope row)
+            if (S.n_lit > block_size) return E_CORRUPT;
+            const int rc = pivco_decode(pdata, lit_comp, scratch, S.n_lit, scratch + block_size + 64u,
+                                        reinterpret_cast<PivLds&>(L), lane);
+            if (rc != 0) return rc;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // literals are read back with L1-cached loads
+            S.lit = scratch;
         }
     } else if (enc_lit == 1u) {
         if (S.n_lit != 0u) {
@@ -751,10 +759,20 @@ __device__ int decode_lz_block(const uint8_t* data, uint32_t comp_sz, bool ghi, 
     const uint64_t sz_off = (uint64_t)S.n_seq * (enc_off ? 1u : 2u);
     const uint64_t consumed = (uint64_t)lit_comp + tok_comp + sz_off;
     if (consumed > avail || avail - lit_comp < 32u) return E_CORRUPT;
-    if (enc_tok == 2u) return ZXC_DEV_E_UNSUPPORTED;  // PivCo token section
-    if (enc_tok != 0u) return E_CORRUPT;
     S.tok = pdata + lit_comp;
-    S.offs = S.tok + tok_comp;
+    if (enc_tok == 2u) {  // level 7: the token bytes are a PivCo section too
+        if (S.n_seq > block_size / 5u + 16u) return E_CORRUPT;
+        uint8_t* tokbuf = scratch + 2u * (block_size + 64u);
+        const int rc = pivco_decode(S.tok, tok_comp, tokbuf, S.n_seq, scratch + block_size + 64u,
+                                    reinterpret_cast<PivLds&>(L), lane);
+        if (rc != 0) return rc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        S.tok = tokbuf;
+    } else if (enc_tok != 0u) {
+        return E_CORRUPT;
+    }
+    S.offs = pdata + lit_comp + tok_comp;
     S.off8 = enc_off;
     S.ext = S.offs + sz_off;
     S.ext_size = avail - (uint32_t)consumed;

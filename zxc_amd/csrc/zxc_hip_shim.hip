@@ -92,7 +92,8 @@ int zxc_mi355x_decode_blocks_device(const void* d_comp, const zxc_dev_job_t* d_j
     }
     uint32_t grid = (uint32_t)g_dev[dev].cus * (uint32_t)g_dev[dev].wg_per_cu;
     if (grid > n_jobs) grid = n_jobs;
-    const uint32_t stride = (block_size + 64u + 255u) & ~255u;
+    // scratch slot: [expanded literals | PivCo ping-pong | decoded tokens]
+    const uint32_t stride = (2u * (block_size + 64u) + block_size / 5u + 16u + 64u + 255u) & ~255u;
     const size_t need = (size_t)grid * stride;
     if (g_dev[dev].bytes < need) {
         if (g_dev[dev].scratch) (void)hipFree(g_dev[dev].scratch);
