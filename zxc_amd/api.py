@@ -26,7 +26,7 @@ class _DecompressOpts(C.Structure):  # include/zxc_opts.h
 
 
 def lib_path():
-    return os.path.join(_HERE, "libzxc_mi355x.so")
+    return os.path.join(_HERE, os.environ.get("ZXC_LIB_VARIANT", "libzxc_mi355x.so"))  # variant: A/B builds for tools/
 
 
 def lib():

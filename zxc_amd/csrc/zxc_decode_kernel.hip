@@ -632,6 +632,39 @@ __device__ int run_sequences(const LzStreams& S, uint8_t* __restrict__ dst, uint
     return (int)p;
 }
 
+// Scratch (expanded literals / PivCo ping-pong / decoded tokens) is only needed by blocks with
+// an RLE or PivCo section. Slots come from a small pool sized to the number of workgroups that
+// can be resident at once, so a free one always exists: lane 0 claims one with atomicCAS.
+struct ScratchPool {
+    uint8_t* base;
+    uint32_t stride;
+    uint32_t* busy;
+    uint32_t n_slots;
+    int held;  // slot index or -1
+};
+__device__ uint8_t* scratch_acquire(ScratchPool& sp, int lane) {
+    if (sp.held < 0) {
+        uint32_t got = 0;
+        if (lane == 0) {
+            uint32_t s = blockIdx.x % sp.n_slots;
+            for (;;) {
+                if (atomicCAS(sp.busy + s, 0u, 1u) == 0u) break;
+                s = (s + 1u == sp.n_slots) ? 0u : s + 1u;
+            }
+            got = s;
+        }
+        sp.held = (int)uni(got);
+    }
+    return sp.base + (size_t)sp.held * sp.stride;
+}
+__device__ void scratch_release(ScratchPool& sp, int lane) {
+    if (sp.held >= 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0) __hip_atomic_store(sp.busy + sp.held, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        sp.held = -1;
+    }
+}
+
 // RLE literal section -> scratch (reference src/lib/zxc_decompress.c:906-975).
 // Tokens form a chain (a raw token skips its payload), so every lane decodes the byte
 // at window position `lane` as if it were a token, and the scalar unit walks the chain
@@ -700,7 +733,7 @@ __device__ int rle_expand(const uint8_t* __restrict__ r, uint32_t rsize, uint8_t
 }
 
 __device__ int decode_lz_block(const uint8_t* data, uint32_t comp_sz, bool ghi, uint8_t* dst, uint32_t out_len,
-                               uint32_t cap, uint32_t block_size, uint8_t* scratch, WaveLds& L, int lane,
+                               uint32_t cap, uint32_t block_size, ScratchPool& pool, WaveLds& L, int lane,
                                uint32_t dbg) {
     if (comp_sz < 12u) return E_BAD_HEADER;
     LzStreams S;
@@ -738,6 +771,7 @@ __device__ int decode_lz_block(const uint8_t* data, uint32_t comp_sz, bool ghi, 
             if (S.n_lit > cap) return E_DST_TOO_SMALL;
             if (enc_lit == 3u) return E_DICT_REQUIRED;  // shared-table sections need a dictionary (next scope row)
             if (S.n_lit > block_size) return E_CORRUPT;
+            uint8_t* scratch = scratch_acquire(pool, lane);
             const int rc = pivco_decode(pdata, lit_comp, scratch, S.n_lit, scratch + block_size + 64u,
                                         reinterpret_cast<PivLds&>(L), lane);
             if (rc != 0) return rc;
@@ -749,6 +783,7 @@ __device__ int decode_lz_block(const uint8_t* data, uint32_t comp_sz, bool ghi, 
         if (S.n_lit != 0u) {
             if (S.n_lit > cap) return E_DST_TOO_SMALL;
             if (S.n_lit > block_size || lit_comp > avail) return E_CORRUPT;
+            uint8_t* scratch = scratch_acquire(pool, lane);
             const int rc = rle_expand(pdata, lit_comp, scratch, S.n_lit, lane);
             if (rc != 0) return rc;
             S.lit = scratch;
@@ -762,6 +797,7 @@ __device__ int decode_lz_block(const uint8_t* data, uint32_t comp_sz, bool ghi, 
     S.tok = pdata + lit_comp;
     if (enc_tok == 2u) {  // level 7: the token bytes are a PivCo section too
         if (S.n_seq > block_size / 5u + 16u) return E_CORRUPT;
+        uint8_t* scratch = scratch_acquire(pool, lane);
         uint8_t* tokbuf = scratch + 2u * (block_size + 64u);
         const int rc = pivco_decode(S.tok, tok_comp, tokbuf, S.n_seq, scratch + block_size + 64u,
                                     reinterpret_cast<PivLds&>(L), lane);
@@ -783,63 +819,55 @@ extern "C" __global__ void __launch_bounds__(64)
 zxc_decode_blocks_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
                          uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,
                          uint32_t trailer_bytes, uint8_t* __restrict__ scratch, uint32_t scratch_stride, uint32_t dbg,
-                         uint32_t* __restrict__ next_job) {
+                         uint32_t* __restrict__ slot_busy, uint32_t n_slots) {
+    // One workgroup (= one wavefront) per block: the hardware dispatcher hands out blocks as
+    // wave slots free up, which is all the dynamic scheduling RAW-vs-dense blocks need.
     __shared__ WaveLds L;
     const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (b >= n_jobs) return;
     const uint32_t cap = block_size + 2112u;  // the reference always decodes with block_size + ZXC_DECOMPRESS_TAIL_PAD
-    uint8_t* my_scratch = scratch + (size_t)blockIdx.x * scratch_stride;
-    uint32_t warm = 0;
-    // Blocks cost very different amounts (RAW vs dense LZ): waves pull the next block index
-    // from one device counter instead of striding (zeroed by the launcher before every launch).
-    for (;;) {
-        uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(next_job, 1u);
-        b = uni(b);
-        if (b >= n_jobs) break;
-        const uint64_t comp_off = jobs[b].comp_off;
-        const uint32_t src_sz = uni(jobs[b].comp_size);
-        const uint32_t out_len = uni(jobs[b].out_len);
-        const uint8_t* src = comp + comp_off;
-        uint8_t* dst = out + jobs[b].out_off;
-        int rc;
-        if (src_sz < 8u) {
+    ScratchPool pool = {scratch, scratch_stride, slot_busy, n_slots, -1};
+    const uint64_t comp_off = jobs[b].comp_off;
+    const uint32_t src_sz = uni(jobs[b].comp_size);
+    const uint32_t out_len = uni(jobs[b].out_len);
+    const uint8_t* src = comp + comp_off;
+    uint8_t* dst = out + jobs[b].out_off;
+    int rc;
+    if (src_sz < 8u) {
+        rc = E_SRC_TOO_SMALL;
+    } else {
+        const uint32_t type = uni(ld8(src));
+        const uint32_t comp_sz = uni(ld32(src + 3));
+        if ((uint64_t)8u + comp_sz + trailer_bytes > src_sz) {
             rc = E_SRC_TOO_SMALL;
-        } else {
-            const uint32_t type = uni(ld8(src));
-            const uint32_t comp_sz = uni(ld32(src + 3));
-            if ((uint64_t)8u + comp_sz + trailer_bytes > src_sz) {
-                rc = E_SRC_TOO_SMALL;
-            } else if (type == 1u || type == 2u) {
-                // pull the block's cache lines toward L2 now; the parse below touches them a batch at a time
-                for (uint32_t o = 128u * lane; o + 4u <= comp_sz; o += 128u * 64u) warm ^= ld32(src + 8 + o);
-                rc = decode_lz_block(src + 8, comp_sz, type == 2u, dst, out_len, cap, block_size, my_scratch, L, lane,
-                                     dbg);
-            } else if (type == 0u) {  // RAW: stored bytes
-                if (comp_sz > cap) rc = E_DST_TOO_SMALL;
-                else {
-                    const uint32_t n = comp_sz < out_len ? comp_sz : out_len;
-                    const uint8_t* s8 = src + 8;
-                    uint32_t i = 16u * lane;
-                    for (; i + 3072u + 16u <= n; i += 4096u) {  // 4 x 1 KiB in flight per wave
-                        const v4u a0 = ld128(s8 + i), a1 = ld128(s8 + i + 1024u), a2 = ld128(s8 + i + 2048u),
-                                  a3 = ld128(s8 + i + 3072u);
-                        *(v4u*)(dst + i) = a0;
-                        *(v4u*)(dst + i + 1024u) = a1;
-                        *(v4u*)(dst + i + 2048u) = a2;
-                        *(v4u*)(dst + i + 3072u) = a3;
-                    }
-                    for (; i + 16u <= n; i += 1024u) *(v4u*)(dst + i) = ld128(s8 + i);
-                    const uint32_t tail = n & ~15u;
-                    if (tail + (uint32_t)lane < n) dst[tail + lane] = s8[tail + lane];
-                    rc = (int)comp_sz;
+        } else if (type == 1u || type == 2u) {
+            rc = decode_lz_block(src + 8, comp_sz, type == 2u, dst, out_len, cap, block_size, pool, L, lane, dbg);
+            scratch_release(pool, lane);
+        } else if (type == 0u) {  // RAW: stored bytes
+            if (comp_sz > cap) rc = E_DST_TOO_SMALL;
+            else {
+                const uint32_t n = comp_sz < out_len ? comp_sz : out_len;
+                const uint8_t* s8 = src + 8;
+                uint32_t i = 16u * lane;
+                for (; i + 3072u + 16u <= n; i += 4096u) {  // 4 x 1 KiB in flight per wave
+                    const v4u a0 = ld128(s8 + i), a1 = ld128(s8 + i + 1024u), a2 = ld128(s8 + i + 2048u),
+                              a3 = ld128(s8 + i + 3072u);
+                    *(v4u*)(dst + i) = a0;
+                    *(v4u*)(dst + i + 1024u) = a1;
+                    *(v4u*)(dst + i + 2048u) = a2;
+                    *(v4u*)(dst + i + 3072u) = a3;
                 }
-            } else if (type == 255u) {
-                rc = E_CORRUPT;
-            } else {
-                rc = E_BAD_BLOCK_TYPE;
+                for (; i + 16u <= n; i += 1024u) *(v4u*)(dst + i) = ld128(s8 + i);
+                const uint32_t tail = n & ~15u;
+                if (tail + (uint32_t)lane < n) dst[tail + lane] = s8[tail + lane];
+                rc = (int)comp_sz;
             }
+        } else if (type == 255u) {
+            rc = E_CORRUPT;
+        } else {
+            rc = E_BAD_BLOCK_TYPE;
         }
-        if (lane == 0) status[b] = rc;
     }
-    if (warm == 0x9E3779B9u && lane == 77) status[0] = (int32_t)warm;  // never true: keeps the warm-up loads alive
+    if (lane == 0) status[b] = rc;
 }

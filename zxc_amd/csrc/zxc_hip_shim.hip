@@ -11,7 +11,7 @@
 extern "C" __global__ void zxc_decode_blocks_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                     uint8_t* out, int32_t* status, uint32_t block_size,
                                                     uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride, uint32_t dbg,
-                                                    uint32_t* next_job);
+                                                    uint32_t* slot_busy, uint32_t n_slots);
 
 // Per-device scratch for expanded literal / token sections: one slot per resident
 // workgroup. Grown on demand, never shrunk; freed at process exit by the driver.
@@ -21,7 +21,7 @@ static struct {
     size_t bytes;
     int cus;
     int wg_per_cu;
-    uint32_t* counter; /* work-queue head */
+    uint32_t* counter; /* scratch-slot busy flags */
 } g_dev[ZXC_MAX_DEVICES];
 
 static uint32_t g_debug_flags = 0;  // timing ablations, set only by zxc_mi355x__set_debug
@@ -83,32 +83,32 @@ int zxc_mi355x_decode_blocks_device(const void* d_comp, const zxc_dev_job_t* d_j
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         g_dev[dev].cus = cus;
     }
-    // One wave per block. Launch exactly as many workgroups as can be resident (LDS- and
-    // register-limited, asked from the runtime once); the kernel grid-strides over the rest.
+    // One workgroup (one wavefront) per block. Scratch slots: one per workgroup that can be
+    // resident at once (LDS/register limited, asked from the runtime), claimed lazily in-kernel.
     if (g_dev[dev].wg_per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, zxc_decode_blocks_kernel, 64, 0) != hipSuccess || nb <= 0) nb = 8;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, zxc_decode_blocks_kernel, 64, 0) != hipSuccess || nb <= 0) nb = 32;
+        if (nb > 32) nb = 32;
         g_dev[dev].wg_per_cu = nb;
     }
-    uint32_t grid = (uint32_t)g_dev[dev].cus * (uint32_t)g_dev[dev].wg_per_cu;
-    if (grid > n_jobs) grid = n_jobs;
+    const uint32_t n_slots = (uint32_t)g_dev[dev].cus * (uint32_t)g_dev[dev].wg_per_cu;
     // scratch slot: [expanded literals | PivCo ping-pong | decoded tokens]
     const uint32_t stride = (2u * (block_size + 64u) + block_size / 5u + 16u + 64u + 255u) & ~255u;
-    const size_t need = (size_t)grid * stride;
+    const size_t need = (size_t)n_slots * stride;
     if (g_dev[dev].bytes < need) {
         if (g_dev[dev].scratch) (void)hipFree(g_dev[dev].scratch);
         g_dev[dev].scratch = NULL;
         g_dev[dev].bytes = 0;
-        // size for a full grid so later, larger calls do not reallocate
-        const size_t want = (size_t)g_dev[dev].cus * (size_t)g_dev[dev].wg_per_cu * stride;
-        if (hipMalloc((void**)&g_dev[dev].scratch, want > need ? want : need) != hipSuccess) return ZXC_ERROR_MEMORY;
-        g_dev[dev].bytes = want > need ? want : need;
+        if (hipMalloc((void**)&g_dev[dev].scratch, need) != hipSuccess) return ZXC_ERROR_MEMORY;
+        g_dev[dev].bytes = need;
     }
-    if (!g_dev[dev].counter && hipMalloc((void**)&g_dev[dev].counter, 256) != hipSuccess) return ZXC_ERROR_MEMORY;
-    if (hipMemsetAsync(g_dev[dev].counter, 0, 4, (hipStream_t)stream) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
-    hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
+    if (!g_dev[dev].counter) {  // slot-busy flags, zero = free; every workgroup releases what it took
+        if (hipMalloc((void**)&g_dev[dev].counter, (size_t)n_slots * 4u) != hipSuccess) return ZXC_ERROR_MEMORY;
+        if (hipMemset(g_dev[dev].counter, 0, (size_t)n_slots * 4u) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
+    }
+    hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
                        d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, verify_trailer ? 4u : 0u,
-                       g_dev[dev].scratch, stride, g_debug_flags, g_dev[dev].counter);
+                       g_dev[dev].scratch, stride, g_debug_flags, g_dev[dev].counter, n_slots);
     return hipGetLastError() == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
 }
 
