@@ -9,7 +9,7 @@
 //      found by a wave-wide scan of 3-state transition maps (the prefix varint is
 //      a 3-state automaton), output/literal cursors by wave prefix sums;
 //   2. copies literals and short matches sequence-per-lane in lockstep into an
-//      LDS ring that holds the last RING_BYTES (8 KiB) of output (the sliding window): the
+//      LDS ring that holds the last RING_BYTES (4 KiB) of output (the sliding window): the
 //      loop counter is wave-uniform, so every step is one LDS read + one LDS write
 //      instruction for all 64 sequences; source dwords are built from aligned LDS
 //      reads + v_alignbyte (unaligned DS accesses replay on gfx950);
@@ -31,7 +31,7 @@ typedef unsigned __int128 u128;
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
 #ifndef RING_BYTES
-#define RING_BYTES 8192u   // sliding window kept in LDS; older history is read back through L2
+#define RING_BYTES 4096u   // sliding window kept in LDS; older history is read back through L2 (A/B: 2/4/8/16 KiB, 4 wins on the silesia mix)
 #endif
 #define RING_MASK (RING_BYTES - 1u)
 #define RING_WORDS (RING_BYTES / 4u)
@@ -815,7 +815,10 @@ __device__ int decode_lz_block(const uint8_t* data, uint32_t comp_sz, bool ghi, 
     return run_sequences(S, dst, out_len, cap, L, lane);
 }
 
-extern "C" __global__ void __launch_bounds__(64)
+#ifndef WAVES_PER_SIMD
+#define WAVES_PER_SIMD 1
+#endif
+extern "C" __global__ void __launch_bounds__(64, WAVES_PER_SIMD)
 zxc_decode_blocks_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
                          uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,
                          uint32_t trailer_bytes, uint8_t* __restrict__ scratch, uint32_t scratch_stride, uint32_t dbg,
