@@ -21,6 +21,13 @@ ZXC_EXPORT const char* zxc_version_string(void);
 /* reference include/zxc_buffer.h:98 (impl src/lib/zxc_common.c:850-862) */
 ZXC_EXPORT uint64_t zxc_compress_bound(const size_t input_size);
 
+/* reference include/zxc_buffer.h:119 (impl src/lib/zxc_dispatch.c:658-818). Whole-buffer
+ * compress into a v8 archive (optionally seekable). Blocks are encoded on the GPU by one
+ * match-finding strategy whatever the level (valid, reference-decodable output; sizes differ
+ * from the CPU encoder's). Returns archive size or a negative zxc_error_t. */
+ZXC_EXPORT int64_t zxc_compress(const void* src, const size_t src_size, void* dst,
+                                const size_t dst_capacity, const zxc_compress_opts_t* opts);
+
 /* reference include/zxc_buffer.h:140 (impl src/lib/zxc_dispatch.c:842-1005).
  * Whole-frame decode: returns decoded size or a negative zxc_error_t. */
 ZXC_EXPORT int64_t zxc_decompress(const void* src, const size_t src_size, void* dst,

@@ -63,6 +63,21 @@ ZXC_EXPORT int zxc_mi355x_decode_blocks_device(const void* d_comp, const zxc_dev
                                                uint32_t n_jobs, void* d_out, int32_t* d_status,
                                                uint32_t block_size, int verify_trailer, void* stream);
 
+/* ---- encode side (LZ77 match finder + GLO serialiser, zxc_amd/csrc/zxc_encode_kernel.hip) ----
+ * Replaces the per-block calls to zxc_compress_chunk_wrapper (src/lib/zxc_compress.c:2041-2074)
+ * made by zxc_compress (src/lib/zxc_dispatch.c:734-780). Block i of the source
+ * (d_src + i*block_size) becomes one complete v8 block (8-byte header + payload, GLO or RAW) at
+ * d_slots + i*zxc_mi355x_encode_slot_stride(block_size); its size lands in d_sizes[i]
+ * (= the seek-table entry). Asynchronous on `stream`. */
+ZXC_EXPORT uint32_t zxc_mi355x_encode_slot_stride(uint32_t block_size);
+ZXC_EXPORT int zxc_mi355x_encode_blocks_device(const void* d_src, uint64_t src_size, uint32_t block_size,
+                                               int level, void* d_slots, uint32_t* d_sizes, void* stream);
+/* Compaction: block i's d_sizes[i] bytes go to d_out + d_offsets[i] (prefix sums computed by the
+ * caller, like seek_comp[] in src/lib/zxc_dispatch.c:761-776). */
+ZXC_EXPORT int zxc_mi355x_gather_blocks_device(const void* d_slots, uint32_t block_size,
+                                               const uint32_t* d_sizes, const uint64_t* d_offsets,
+                                               void* d_out, uint32_t n_blocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

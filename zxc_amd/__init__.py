@@ -5,5 +5,5 @@ The product is ``libzxc_mi355x.so`` (HIP kernels + C host API, built by
 ctypes view of its C-ABI used by tests and bench.py. There is no Python or CPU
 decoder behind it: if the library or a GPU is missing, calls raise.
 """
-from .api import (ZxcError, Seekable, decompress, get_decompressed_size, decode_blocks_device,  # noqa: F401
+from .api import (ZxcError, Seekable, compress, decompress, get_decompressed_size, decode_blocks_device,  # noqa: F401
                   lib, lib_path, JOB_DTYPE, error_name)

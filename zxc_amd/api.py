@@ -19,6 +19,13 @@ class ZxcError(RuntimeError):
         super().__init__(f"{what}: {error_name(self.code)} ({self.code})")
 
 
+class _CompressOpts(C.Structure):  # include/zxc_opts.h
+    _fields_ = [("n_threads", C.c_int), ("level", C.c_int), ("block_size", C.c_size_t),
+                ("checksum_enabled", C.c_int), ("seekable", C.c_int), ("dict", C.c_void_p),
+                ("dict_size", C.c_size_t), ("dict_huf", C.c_void_p), ("progress_cb", C.c_void_p),
+                ("user_data", C.c_void_p)]
+
+
 class _DecompressOpts(C.Structure):  # include/zxc_opts.h
     _fields_ = [("n_threads", C.c_int), ("checksum_enabled", C.c_int), ("dict", C.c_void_p),
                 ("dict_size", C.c_size_t), ("dict_huf", C.c_void_p), ("progress_cb", C.c_void_p),
@@ -41,6 +48,13 @@ def lib():
         L.zxc_error_name.argtypes = [C.c_int]
         L.zxc_decompress.restype = C.c_int64
         L.zxc_decompress.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(_DecompressOpts)]
+        L.zxc_compress.restype = C.c_int64
+        L.zxc_compress.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(_CompressOpts)]
+        L.zxc_mi355x_encode_slot_stride.restype = C.c_uint32
+        L.zxc_mi355x_encode_slot_stride.argtypes = [C.c_uint32]
+        L.zxc_mi355x_encode_blocks_device.restype = C.c_int
+        L.zxc_mi355x_encode_blocks_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p,
+                                                      C.c_void_p, C.c_void_p]
         L.zxc_get_decompressed_size.restype = C.c_uint64
         L.zxc_get_decompressed_size.argtypes = [C.c_char_p, C.c_size_t]
         L.zxc_compress_bound.restype = C.c_uint64
@@ -81,6 +95,19 @@ def error_name(code):
 
 def get_decompressed_size(comp: bytes) -> int:
     return int(lib().zxc_get_decompressed_size(comp, len(comp)))
+
+
+def compress(data: bytes, level=3, block_size=65536, seekable=True, checksum=False, raise_on_error=True):
+    """zxc_compress(): host buffer in, v8 archive out (blocks encoded on the GPU)."""
+    o = _CompressOpts(level=level, block_size=block_size, seekable=int(seekable), checksum_enabled=int(checksum))
+    cap = int(lib().zxc_compress_bound(len(data)))
+    out = C.create_string_buffer(max(cap, 64))
+    rc = lib().zxc_compress(data, len(data), out, cap, C.byref(o))
+    if rc < 0:
+        if raise_on_error:
+            raise ZxcError(rc, "zxc_compress")
+        return rc, b""
+    return out.raw[:rc] if raise_on_error else (rc, out.raw[:rc])
 
 
 def decompress(comp: bytes, capacity=None, checksum=False, raise_on_error=True):

@@ -13,6 +13,11 @@ extern "C" __global__ void zxc_decode_blocks_kernel(const uint8_t* comp, const z
                                                     uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride, uint32_t dbg,
                                                     uint32_t* slot_busy, uint32_t n_slots);
 
+extern "C" __global__ void zxc_encode_blocks_kernel(const uint8_t* src, uint64_t src_size, uint32_t block_size, uint8_t* slots,
+                                                    uint32_t slot_stride, uint32_t* sizes, uint32_t n_blocks);
+extern "C" __global__ void zxc_gather_blocks_kernel(const uint8_t* slots, uint32_t slot_stride, const uint32_t* sizes,
+                                                    const uint64_t* offsets, uint8_t* out, uint32_t n_blocks);
+
 // Per-device scratch for expanded literal / token sections: one slot per resident
 // workgroup. Grown on demand, never shrunk; freed at process exit by the driver.
 #define ZXC_MAX_DEVICES 16
@@ -109,6 +114,32 @@ int zxc_mi355x_decode_blocks_device(const void* d_comp, const zxc_dev_job_t* d_j
     hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
                        d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, verify_trailer ? 4u : 0u,
                        g_dev[dev].scratch, stride, g_debug_flags, g_dev[dev].counter, n_slots);
+    return hipGetLastError() == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
+}
+
+uint32_t zxc_mi355x_encode_slot_stride(uint32_t block_size) { return 2u * block_size + 512u; }
+
+int zxc_mi355x_encode_blocks_device(const void* d_src, uint64_t src_size, uint32_t block_size, int level, void* d_slots,
+                                    uint32_t* d_sizes, void* stream) {
+    (void)level;  // one match-finding strategy for every level (see zxc_encode_kernel.hip)
+    if (src_size == 0) return ZXC_OK;
+    if (!d_src || !d_slots || !d_sizes) return ZXC_ERROR_NULL_INPUT;
+    if (block_size < (1u << 12) || block_size > (1u << 21) || (block_size & (block_size - 1u))) return ZXC_ERROR_BAD_BLOCK_SIZE;
+    if (current_device() < 0) return ZXC_ERROR_GPU_UNAVAILABLE;
+    const uint64_t nb64 = (src_size + block_size - 1u) / block_size;
+    if (nb64 > 0x7FFFFFFFull) return ZXC_ERROR_BAD_BLOCK_SIZE;
+    const uint32_t nb = (uint32_t)nb64;
+    hipLaunchKernelGGL(zxc_encode_blocks_kernel, dim3(nb), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_src, src_size,
+                       block_size, (uint8_t*)d_slots, zxc_mi355x_encode_slot_stride(block_size), d_sizes, nb);
+    return hipGetLastError() == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
+}
+
+int zxc_mi355x_gather_blocks_device(const void* d_slots, uint32_t block_size, const uint32_t* d_sizes,
+                                    const uint64_t* d_offsets, void* d_out, uint32_t n_blocks, void* stream) {
+    if (n_blocks == 0) return ZXC_OK;
+    if (!d_slots || !d_sizes || !d_offsets || !d_out) return ZXC_ERROR_NULL_INPUT;
+    hipLaunchKernelGGL(zxc_gather_blocks_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_slots,
+                       zxc_mi355x_encode_slot_stride(block_size), d_sizes, d_offsets, (uint8_t*)d_out, n_blocks);
     return hipGetLastError() == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
 }
 

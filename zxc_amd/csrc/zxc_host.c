@@ -6,6 +6,7 @@
  * there is no CPU decoder in this library and no fallback: without a usable HIP
  * device the calls fail with ZXC_ERROR_GPU_UNAVAILABLE.
  *
+ *   zxc_compress                      <- src/lib/zxc_dispatch.c:658-818
  *   zxc_decompress                    <- src/lib/zxc_dispatch.c:842-1005
  *   zxc_get_decompressed_size         <- src/lib/zxc_dispatch.c:1203-1225
  *   zxc_seekable_open / _open_reader  <- src/lib/zxc_seekable.c:270-554
@@ -278,6 +279,107 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
         if (rd64(src + src_size - ZXC_FILE_FOOTER_SIZE) != (uint64_t)total) return ZXC_ERROR_CORRUPT_DATA;
     }
     return (int64_t)total;
+}
+
+/* ------------------------------------------------------------ zxc_compress */
+static void wr64(uint8_t* p, uint64_t v) {
+    wr32(p, (uint32_t)v);
+    wr32(p + 4, (uint32_t)(v >> 32));
+}
+
+int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const size_t dst_capacity,
+                     const zxc_compress_opts_t* opts) {
+    uint8_t* dst = (uint8_t*)dst_v;
+    if (!dst || dst_capacity == 0 || (src_size > 0 && !src)) return ZXC_ERROR_NULL_INPUT;
+    const int checksum_enabled = opts ? opts->checksum_enabled : 0;
+    const int seekable = opts ? opts->seekable : 0;
+    int level = (opts && opts->level > 0) ? opts->level : ZXC_LEVEL_DEFAULT;
+    if (level > ZXC_LEVEL_ULTRA) level = ZXC_LEVEL_ULTRA;
+    const size_t block_size = (opts && opts->block_size > 0) ? opts->block_size : ZXC_BLOCK_SIZE_DEFAULT;
+    const size_t dict_size = (opts && opts->dict) ? opts->dict_size : 0;
+    if (dict_size > ZXC_DICT_SIZE_MAX) return ZXC_ERROR_DICT_TOO_LARGE;
+    if (block_size < ZXC_BLOCK_SIZE_MIN || block_size > ZXC_BLOCK_SIZE_MAX || (block_size & (block_size - 1)))
+        return ZXC_ERROR_BAD_BLOCK_SIZE;
+    if (dict_size != 0 || checksum_enabled) return ZXC_ERROR_GPU_UNSUPPORTED; /* next scope rows */
+    if (dst_capacity < ZXC_FILE_HEADER_SIZE) return ZXC_ERROR_DST_TOO_SMALL;
+
+    /* file header (src/lib/zxc_common.c:534-558) */
+    memset(dst, 0, ZXC_FILE_HEADER_SIZE);
+    wr32(dst, MAGIC);
+    dst[4] = FORMAT_VERSION;
+    uint8_t lg = 0;
+    while (((size_t)1 << lg) < block_size) lg++;
+    dst[5] = lg;
+    const uint16_t crc = hdr_hash16(dst);
+    dst[14] = (uint8_t)crc;
+    dst[15] = (uint8_t)(crc >> 8);
+    size_t op = ZXC_FILE_HEADER_SIZE;
+
+    const uint64_t nb64 = ((uint64_t)src_size + block_size - 1) / block_size;
+    if (nb64 > 0x7FFFFFFFull) return ZXC_ERROR_BAD_BLOCK_SIZE;
+    const uint32_t nb = (uint32_t)nb64;
+    uint32_t* sizes = NULL;
+    if (nb > 0) {
+        if (zxc_mi355x_device_count() <= 0) return ZXC_ERROR_GPU_UNAVAILABLE;
+        const uint32_t stride = zxc_mi355x_encode_slot_stride((uint32_t)block_size);
+        sizes = (uint32_t*)malloc((size_t)nb * sizeof(uint32_t));
+        uint64_t* offs = (uint64_t*)malloc((size_t)nb * sizeof(uint64_t));
+        void* d_src = zxc_mi355x_malloc(src_size + 64);
+        void* d_slots = zxc_mi355x_malloc((size_t)nb * stride);
+        void* d_sizes = zxc_mi355x_malloc((size_t)nb * 4);
+        void* d_offs = zxc_mi355x_malloc((size_t)nb * 8);
+        void* d_out = NULL;
+        int64_t rc = ZXC_ERROR_MEMORY;
+        if (sizes && offs && d_src && d_slots && d_sizes && d_offs) {
+            rc = zxc_mi355x_memcpy_h2d(d_src, src, src_size);
+            if (rc == ZXC_OK)
+                rc = zxc_mi355x_encode_blocks_device(d_src, src_size, (uint32_t)block_size, level, d_slots,
+                                                     (uint32_t*)d_sizes, NULL);
+            if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(NULL);
+            if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(sizes, d_sizes, (size_t)nb * 4);
+            uint64_t total = 0;
+            if (rc == ZXC_OK) {
+                for (uint32_t i = 0; i < nb; i++) { offs[i] = total; total += sizes[i]; }
+                const uint64_t need = op + total + BLK_HDR + (seekable ? zxc_seek_table_size(nb) : 0) + ZXC_FILE_FOOTER_SIZE;
+                if (need > dst_capacity) rc = ZXC_ERROR_DST_TOO_SMALL;
+            }
+            if (rc == ZXC_OK) {
+                d_out = zxc_mi355x_malloc((size_t)total + 64);
+                if (!d_out) rc = ZXC_ERROR_MEMORY;
+            }
+            if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_h2d(d_offs, offs, (size_t)nb * 8);
+            if (rc == ZXC_OK)
+                rc = zxc_mi355x_gather_blocks_device(d_slots, (uint32_t)block_size, (const uint32_t*)d_sizes,
+                                                     (const uint64_t*)d_offs, d_out, nb, NULL);
+            if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(NULL);
+            if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(dst + op, d_out, (size_t)total);
+            if (rc == ZXC_OK) op += (size_t)total;
+        }
+        zxc_mi355x_free(d_src);
+        zxc_mi355x_free(d_slots);
+        zxc_mi355x_free(d_sizes);
+        zxc_mi355x_free(d_offs);
+        zxc_mi355x_free(d_out);
+        free(offs);
+        if (rc != ZXC_OK) { free(sizes); return rc; }
+    }
+    /* EOF block, optional seek table, footer (src/lib/zxc_dispatch.c:784-815) */
+    if (dst_capacity - op < BLK_HDR) { free(sizes); return ZXC_ERROR_DST_TOO_SMALL; }
+    memset(dst + op, 0, BLK_HDR);
+    dst[op] = BLK_EOF;
+    dst[op + 7] = hdr_hash8(dst + op);
+    op += BLK_HDR;
+    if (seekable && nb > 0) {
+        const int64_t st = zxc_write_seek_table(dst + op, dst_capacity - op, sizes, nb);
+        if (st < 0) { free(sizes); return st; }
+        op += (size_t)st;
+    }
+    free(sizes);
+    if (dst_capacity - op < ZXC_FILE_FOOTER_SIZE) return ZXC_ERROR_DST_TOO_SMALL;
+    wr64(dst + op, (uint64_t)src_size);
+    wr32(dst + op + 8, 0); /* global hash: zero when checksums are off */
+    op += ZXC_FILE_FOOTER_SIZE;
+    return (int64_t)op;
 }
 
 /* ---------------------------------------------------------------- seekable */
