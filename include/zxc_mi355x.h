@@ -58,7 +58,8 @@ ZXC_EXPORT int64_t zxc_mi355x_plan_seekable(const zxc_seekable* s, uint32_t firs
  * readable/writable up to round_up(out_off + out_len, 16) + 16. block_size is the
  * archive's block size (bounds scratch and the per-block output cap
  * block_size + 2112, like the reference). verify_trailer = 1 means every block
- * carries and is bound-checked with its 4-byte checksum trailer. */
+ * carries its 4-byte checksum trailer and it is verified on device (rapidhash of the
+ * payload, ZXC_ERROR_BAD_CHECKSUM on mismatch). */
 ZXC_EXPORT int zxc_mi355x_decode_blocks_device(const void* d_comp, const zxc_dev_job_t* d_jobs,
                                                uint32_t n_jobs, void* d_out, int32_t* d_status,
                                                uint32_t block_size, int verify_trailer, void* stream);
@@ -68,10 +69,11 @@ ZXC_EXPORT int zxc_mi355x_decode_blocks_device(const void* d_comp, const zxc_dev
  * made by zxc_compress (src/lib/zxc_dispatch.c:734-780). Block i of the source
  * (d_src + i*block_size) becomes one complete v8 block (8-byte header + payload, GLO or RAW) at
  * d_slots + i*zxc_mi355x_encode_slot_stride(block_size); its size lands in d_sizes[i]
- * (= the seek-table entry). Asynchronous on `stream`. */
+ * (= the seek-table entry; with_checksum appends the 4-byte rapidhash trailer). Asynchronous on `stream`. */
 ZXC_EXPORT uint32_t zxc_mi355x_encode_slot_stride(uint32_t block_size);
 ZXC_EXPORT int zxc_mi355x_encode_blocks_device(const void* d_src, uint64_t src_size, uint32_t block_size,
-                                               int level, void* d_slots, uint32_t* d_sizes, void* stream);
+                                               int level, int with_checksum, void* d_slots,
+                                               uint32_t* d_sizes, void* stream);
 /* Compaction: block i's d_sizes[i] bytes go to d_out + d_offsets[i] (prefix sums computed by the
  * caller, like seek_comp[] in src/lib/zxc_dispatch.c:761-776). */
 ZXC_EXPORT int zxc_mi355x_gather_blocks_device(const void* d_slots, uint32_t block_size,

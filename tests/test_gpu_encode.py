@@ -18,17 +18,24 @@ def gpu(product):
     return product
 
 
-def _check(gpu, oracle, ref, data, level=3, block_size=65536, seekable=True):
-    comp = gpu.compress(data, level, block_size, seekable)
+def _check(gpu, oracle, ref, data, level=3, block_size=65536, seekable=True, checksum=False):
+    comp = gpu.compress(data, level, block_size, seekable, checksum)
     assert gpu.get_decompressed_size(comp) == len(data)
     if ref is not None:
-        rc, out = ref.decompress(comp, len(data))
+        rc, out = ref.decompress(comp, len(data), checksum=checksum)
         assert rc == len(data) and out == data, "reference decoder rejects / differs"
-    rc, out = oracle.decompress(comp, len(data))
+    rc, out = oracle.decompress(comp, len(data), checksum=checksum)
     assert rc == len(data) and out == data
     if len(data):
-        assert gpu.decompress(comp) == data
+        assert gpu.decompress(comp, checksum=checksum) == data
     return comp
+
+
+def test_checksummed_archives(gpu, oracle, ref, synth_inputs):
+    """Per-block rapidhash trailers + global hash written by the device path verify in the reference."""
+    for name in ("mixed_384k", "seek_70001", "zeros_130k"):
+        _check(gpu, oracle, ref, synth_inputs[name], 3, 65536, True, checksum=True)
+    _check(gpu, oracle, ref, b"x" * 10, 3, 4096, False, checksum=True)
 
 
 def test_roundtrip_generators(gpu, oracle, ref, synth_inputs):

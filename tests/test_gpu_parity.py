@@ -32,7 +32,7 @@ def gpu(product):
 def test_conformance_valid(gpu, oracle, name):
     comp = read(f"conformance/valid/{name}.zxc")
     exp = read(f"conformance/valid/{name}.expected")
-    rc, out = gpu.decompress(comp, len(exp), raise_on_error=False)
+    rc, out = gpu.decompress(comp, len(exp), checksum=True, raise_on_error=False)
     if name.startswith("dict_"):
         assert rc in (-15, UNSUPPORTED)  # dictionary archives: next scope row, must not decode silently
         return
@@ -40,11 +40,8 @@ def test_conformance_valid(gpu, oracle, name):
 
 
 def test_conformance_invalid(gpu, manifest):
-    needs_checksum = {"bad_block_checksum", "corrupt_payload"}
     for f, meta in manifest["conformance_invalid"].items():
-        if f[:-4] in needs_checksum:
-            continue  # device rapidhash verification: next scope row
-        rc, _ = gpu.decompress(read(f"conformance/invalid/{f}"), 1 << 20, raise_on_error=False)
+        rc, _ = gpu.decompress(read(f"conformance/invalid/{f}"), 1 << 20, checksum=True, raise_on_error=False)
         assert rc == meta["expect"], f
 
 
@@ -63,15 +60,13 @@ def test_format_golden(gpu, manifest):
 def test_synth_archives_all_levels(gpu, manifest, synth_inputs):
     seen_ok = 0
     for name, meta in manifest["synth"].items():
-        if meta["checksum"]:
-            continue
         comp = read(f"synth/{name}.zxc")
         data = synth_inputs[meta["input"]]
-        rc, out = gpu.decompress(comp, len(data), raise_on_error=False)
+        rc, out = gpu.decompress(comp, len(data), checksum=bool(meta["checksum"]), raise_on_error=False)
         assert rc == len(data), (name, rc)
         assert out == data, name
         seen_ok += 1
-    assert seen_ok >= 14
+    assert seen_ok >= 16
 
 
 def test_seekable_ranges(gpu, manifest, synth_inputs):
@@ -122,3 +117,21 @@ def test_large_corpus_roundtrip_properties(gpu, ref):
         out = s.decompress_range(0, len(data))
         assert hashlib.sha256(out).digest() == hashlib.sha256(data).digest(), level
         s.close()
+
+
+def test_checksum_verification(gpu, oracle, manifest):
+    """Device rapidhash: a flipped payload bit must be caught as BAD_CHECKSUM (-7) when verification is
+    requested, exactly like the oracle; the footer's global hash is checked too."""
+    comp = bytearray(read("synth/text_300k_l1_b128k_ck.zxc"))
+    size = manifest["synth"]["text_300k_l1_b128k_ck"]["size"]
+    rng = random.Random(2)
+    for _ in range(12):
+        m = bytearray(comp)
+        m[rng.randrange(40, len(m) - 40)] ^= 1 << rng.randrange(8)
+        a, _ = oracle.decompress(bytes(m), size, checksum=True)
+        b, _ = gpu.decompress(bytes(m), size, checksum=True, raise_on_error=False)
+        assert a == b
+    m = bytearray(comp)
+    m[-1] ^= 0x40  # global hash in the footer
+    assert gpu.decompress(bytes(m), size, checksum=True, raise_on_error=False)[0] == -7
+    assert gpu.decompress(bytes(m), size, checksum=False) is not None

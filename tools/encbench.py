@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Config 3: encoder (match finder + serialise) throughput, device-resident, 64 KiB blocks.
+Env: EB_MIB (base text MiB, default 64), EB_TILES (default 16 -> 1 GiB)."""
+import os, sys, time, ctypes as C
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import torch, zxc_amd
+from zxc_amd import corpus
+mib = int(os.environ.get("EB_MIB", "64")); tiles = int(os.environ.get("EB_TILES", "16")); bs = 65536
+data = corpus.synth_text(mib << 20, seed=1)
+dev = torch.device("cuda", 0)
+base = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+d_src = base.repeat(tiles)
+n = d_src.numel(); nb = (n + bs - 1) // bs
+L = zxc_amd.lib()
+stride = L.zxc_mi355x_encode_slot_stride(bs)
+d_slots = torch.empty(nb * stride, dtype=torch.uint8, device=dev)
+d_sizes = torch.zeros(nb, dtype=torch.int32, device=dev)
+stream = torch.cuda.current_stream().cuda_stream
+def step():
+    rc = L.zxc_mi355x_encode_blocks_device(C.c_void_p(d_src.data_ptr()), n, bs, 3, 0, C.c_void_p(d_slots.data_ptr()), C.c_void_p(d_sizes.data_ptr()), C.c_void_p(stream))
+    assert rc == 0, rc
+step(); torch.cuda.synchronize()
+e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(3): step()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 3
+csize = int(d_sizes.sum().item())
+print(f"encode {n>>20} MiB in {ms:.2f} ms = {n/ms/1e6:.1f} GB/s source; compressed {csize} B ratio {n/csize:.3f}")
+# CPU reference: level 3, one thread, on the base text (bounded sample)
+import oracle_py
+if oracle_py.Ref.available():
+    ref = oracle_py.Ref(); sample = data[:32 << 20]
+    t = time.perf_counter(); c = ref.compress(sample, 3, bs, True, False); dt = time.perf_counter() - t
+    print(f"reference zxc_compress level 3, 1 thread, {len(sample)>>20} MiB: {len(sample)/dt/1e6:.0f} MB/s, ratio {len(sample)/len(c):.3f}")
+    # round trip of the device output for the first tile through the reference decoder
+    comp = zxc_amd.compress(sample, 3, bs, True)
+    rc, out = ref.decompress(comp, len(sample)); print("round trip vs reference decoder:", rc == len(sample) and out == sample)

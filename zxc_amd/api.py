@@ -53,8 +53,8 @@ def lib():
         L.zxc_mi355x_encode_slot_stride.restype = C.c_uint32
         L.zxc_mi355x_encode_slot_stride.argtypes = [C.c_uint32]
         L.zxc_mi355x_encode_blocks_device.restype = C.c_int
-        L.zxc_mi355x_encode_blocks_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p,
-                                                      C.c_void_p, C.c_void_p]
+        L.zxc_mi355x_encode_blocks_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int,
+                                                      C.c_void_p, C.c_void_p, C.c_void_p]
         L.zxc_get_decompressed_size.restype = C.c_uint64
         L.zxc_get_decompressed_size.argtypes = [C.c_char_p, C.c_size_t]
         L.zxc_compress_bound.restype = C.c_uint64

@@ -44,6 +44,7 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 #define E_DST_TOO_SMALL (-2)
 #define E_SRC_TOO_SMALL (-3)
 #define E_BAD_HEADER (-6)
+#define E_BAD_CHECKSUM (-7)
 #define E_CORRUPT (-8)
 #define E_BAD_OFFSET (-9)
 #define E_OVERFLOW (-10)
@@ -351,6 +352,7 @@ __device__ uint32_t parse_varints(const uint8_t* ext, uint32_t ext_size, uint32_
 }
 
 #include "zxc_pivco.inc"
+#include "zxc_rapidhash.inc"
 
 // ------------------------------------------------------------------ block decode
 struct LzStreams {
@@ -825,7 +827,8 @@ zxc_decode_blocks_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* 
                          uint32_t* __restrict__ slot_busy, uint32_t n_slots) {
     // One workgroup (= one wavefront) per block: the hardware dispatcher hands out blocks as
     // wave slots free up, which is all the dynamic scheduling RAW-vs-dense blocks need.
-    __shared__ WaveLds L;
+    __shared__ union { WaveLds w; PivLds p; } lds;  // the PivCo tables reuse the ring's LDS (never live together)
+    WaveLds& L = lds.w;
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (b >= n_jobs) return;
@@ -844,6 +847,8 @@ zxc_decode_blocks_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* 
         const uint32_t comp_sz = uni(ld32(src + 3));
         if ((uint64_t)8u + comp_sz + trailer_bytes > src_sz) {
             rc = E_SRC_TOO_SMALL;
+        } else if (trailer_bytes && wave_checksum32(src + 8, comp_sz, lane) != uni(ld32(src + 8 + comp_sz))) {
+            rc = E_BAD_CHECKSUM;  // per-block checksum of the compressed payload (zxc_decompress.c:1662-1666)
         } else if (type == 1u || type == 2u) {
             rc = decode_lz_block(src + 8, comp_sz, type == 2u, dst, out_len, cap, block_size, pool, L, lane, dbg);
             scratch_release(pool, lane);

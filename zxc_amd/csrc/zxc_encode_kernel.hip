@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "zxc_dev.h"
+#include "zxc_rapidhash.inc"
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
@@ -101,7 +102,7 @@ __device__ void wave_move_down(uint8_t* dst, const uint8_t* src, uint32_t n, int
 extern "C" __global__ void __launch_bounds__(64)
 zxc_encode_blocks_kernel(const uint8_t* __restrict__ src, uint64_t src_size, uint32_t block_size,
                          uint8_t* __restrict__ slots, uint32_t slot_stride, uint32_t* __restrict__ sizes,
-                         uint32_t n_blocks) {
+                         uint32_t n_blocks, uint32_t with_checksum) {
     __shared__ uint32_t ht[ENC_HSIZE];
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
@@ -254,8 +255,17 @@ zxc_encode_blocks_kernel(const uint8_t* __restrict__ src, uint64_t src_size, uin
             const uint8_t crc = hdr_hash8(hv);
             hv |= (uint64_t)crc << 56;
             __builtin_memcpy(slot, &hv, 8);
-            sizes[b] = 8u + n;
         }
+        uint32_t total = 8u + n;
+        if (with_checksum) {  // trailer = checksum of the payload (zxc_compress.c:2060-2071); read back through L2
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const uint32_t ck = wave_checksum32(slot + 8, n, lane);
+            if (lane == 0) __builtin_memcpy(slot + total, &ck, 4);
+            total += 4u;
+        }
+        if (lane == 0) sizes[b] = total;
         return;
     }
     uint8_t* w = slot + 20 + lit_count;
@@ -277,8 +287,17 @@ zxc_encode_blocks_kernel(const uint8_t* __restrict__ src, uint64_t src_size, uin
         __builtin_memcpy(slot, &hv, 8);
         uint32_t gh[3] = {seq_count, lit_count, (uint32_t)(off8 ? 1u : 0u) << 24};  // enc_lit 0, enc_tok 0, enc_mlen 0, enc_off
         __builtin_memcpy(slot + 8, gh, 12);
-        sizes[b] = 8u + payload;
     }
+    uint32_t total = 8u + payload;
+    if (with_checksum) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const uint32_t ck = wave_checksum32(slot + 8, payload, lane);
+        if (lane == 0) __builtin_memcpy(slot + total, &ck, 4);
+        total += 4u;
+    }
+    if (lane == 0) sizes[b] = total;
 }
 
 // Compaction: block b's bytes [slot, slot+sizes[b]) -> out + offsets[b] (+ optional 4-byte trailer gap).

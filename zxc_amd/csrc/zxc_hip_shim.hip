@@ -14,7 +14,7 @@ extern "C" __global__ void zxc_decode_blocks_kernel(const uint8_t* comp, const z
                                                     uint32_t* slot_busy, uint32_t n_slots);
 
 extern "C" __global__ void zxc_encode_blocks_kernel(const uint8_t* src, uint64_t src_size, uint32_t block_size, uint8_t* slots,
-                                                    uint32_t slot_stride, uint32_t* sizes, uint32_t n_blocks);
+                                                    uint32_t slot_stride, uint32_t* sizes, uint32_t n_blocks, uint32_t with_checksum);
 extern "C" __global__ void zxc_gather_blocks_kernel(const uint8_t* slots, uint32_t slot_stride, const uint32_t* sizes,
                                                     const uint64_t* offsets, uint8_t* out, uint32_t n_blocks);
 
@@ -119,8 +119,8 @@ int zxc_mi355x_decode_blocks_device(const void* d_comp, const zxc_dev_job_t* d_j
 
 uint32_t zxc_mi355x_encode_slot_stride(uint32_t block_size) { return 2u * block_size + 512u; }
 
-int zxc_mi355x_encode_blocks_device(const void* d_src, uint64_t src_size, uint32_t block_size, int level, void* d_slots,
-                                    uint32_t* d_sizes, void* stream) {
+int zxc_mi355x_encode_blocks_device(const void* d_src, uint64_t src_size, uint32_t block_size, int level,
+                                    int with_checksum, void* d_slots, uint32_t* d_sizes, void* stream) {
     (void)level;  // one match-finding strategy for every level (see zxc_encode_kernel.hip)
     if (src_size == 0) return ZXC_OK;
     if (!d_src || !d_slots || !d_sizes) return ZXC_ERROR_NULL_INPUT;
@@ -130,7 +130,8 @@ int zxc_mi355x_encode_blocks_device(const void* d_src, uint64_t src_size, uint32
     if (nb64 > 0x7FFFFFFFull) return ZXC_ERROR_BAD_BLOCK_SIZE;
     const uint32_t nb = (uint32_t)nb64;
     hipLaunchKernelGGL(zxc_encode_blocks_kernel, dim3(nb), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_src, src_size,
-                       block_size, (uint8_t*)d_slots, zxc_mi355x_encode_slot_stride(block_size), d_sizes, nb);
+                       block_size, (uint8_t*)d_slots, zxc_mi355x_encode_slot_stride(block_size), d_sizes, nb,
+                       with_checksum ? 1u : 0u);
     return hipGetLastError() == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
 }
 

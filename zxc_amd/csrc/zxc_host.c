@@ -197,7 +197,6 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
     const size_t dict_size = (opts && opts->dict) ? opts->dict_size : 0;
     if (dict_id != 0 && (!dict || dict_size == 0)) return ZXC_ERROR_DICT_REQUIRED;
     if (dict_id != 0 || dict_size != 0) return ZXC_ERROR_GPU_UNSUPPORTED; /* dictionary prefix: next scope row */
-    if (verify) return ZXC_ERROR_GPU_UNSUPPORTED;                         /* device rapidhash: next scope row */
 
     /* Pass 1 (host): walk the 8-byte block headers into a job table. A problem found
      * at block k is only reported if blocks 0..k-1 all decode (the reference stops at
@@ -207,6 +206,7 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
     if (!jobs) return ZXC_ERROR_MEMORY;
     size_t ip = ZXC_FILE_HEADER_SIZE;
     int tail_err = 0;     /* error to report after all queued blocks succeed */
+    uint32_t global_hash = 0; /* rotl1-xor fold of the stored per-block checksums (zxc_internal.h:1390-1393) */
     int saw_eof = 0;
     while (ip < src_size) {
         const size_t rem = src_size - ip;
@@ -229,6 +229,8 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
         jobs[n].out_off = (uint64_t)n * block_size;
         jobs[n].out_len = block_size;
         n++;
+        if (verify && (size_t)BLK_HDR + csz + 4 <= rem)
+            global_hash = ((global_hash << 1) | (global_hash >> 31)) ^ rd32(src + ip + BLK_HDR + csz);
         ip += (size_t)BLK_HDR + csz + (file_ck ? 4 : 0);
     }
 
@@ -238,7 +240,7 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
         int32_t* st = (int32_t*)malloc((size_t)n * sizeof(int32_t));
         if (!st) { free(jobs); return ZXC_ERROR_MEMORY; }
         dev_bufs_t b;
-        int rc = run_jobs(src, src_size, jobs, n, (size_t)n * block_size, block_size, 0, st, &b);
+        int rc = run_jobs(src, src_size, jobs, n, (size_t)n * block_size, block_size, verify, st, &b);
         if (rc != ZXC_OK) { free(st); free(jobs); return rc; }
         /* sequential semantics: first failing block wins; sizes accumulate in order */
         int regular = 1;
@@ -257,7 +259,7 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
             dev_bufs_free(&b);
             const uint32_t slot = (block_size + TAIL_PAD + 15u) & ~15u;
             for (uint32_t i = 0; i < n; i++) { jobs[i].out_off = (uint64_t)i * slot; jobs[i].out_len = slot; }
-            rc = run_jobs(src, src_size, jobs, n, (size_t)n * slot, block_size, 0, st, &b);
+            rc = run_jobs(src, src_size, jobs, n, (size_t)n * slot, block_size, verify, st, &b);
             if (rc != ZXC_OK) { free(st); free(jobs); return rc; }
             size_t op = 0;
             for (uint32_t i = 0; i < n && rc == ZXC_OK; i++) {
@@ -276,7 +278,9 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
     free(jobs);
     if (tail_err) return tail_err;
     if (saw_eof) { /* footer: stored size must equal what was produced (zxc_dispatch.c:936-943) */
-        if (rd64(src + src_size - ZXC_FILE_FOOTER_SIZE) != (uint64_t)total) return ZXC_ERROR_CORRUPT_DATA;
+        const uint8_t* footer = src + src_size - ZXC_FILE_FOOTER_SIZE;
+        if (rd64(footer) != (uint64_t)total) return ZXC_ERROR_CORRUPT_DATA;
+        if (verify && rd32(footer + 8) != global_hash) return ZXC_ERROR_BAD_CHECKSUM; /* :945-952 */
     }
     return (int64_t)total;
 }
@@ -300,7 +304,7 @@ int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const 
     if (dict_size > ZXC_DICT_SIZE_MAX) return ZXC_ERROR_DICT_TOO_LARGE;
     if (block_size < ZXC_BLOCK_SIZE_MIN || block_size > ZXC_BLOCK_SIZE_MAX || (block_size & (block_size - 1)))
         return ZXC_ERROR_BAD_BLOCK_SIZE;
-    if (dict_size != 0 || checksum_enabled) return ZXC_ERROR_GPU_UNSUPPORTED; /* next scope rows */
+    if (dict_size != 0) return ZXC_ERROR_GPU_UNSUPPORTED; /* dictionary: next scope row */
     if (dst_capacity < ZXC_FILE_HEADER_SIZE) return ZXC_ERROR_DST_TOO_SMALL;
 
     /* file header (src/lib/zxc_common.c:534-558) */
@@ -310,6 +314,7 @@ int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const 
     uint8_t lg = 0;
     while (((size_t)1 << lg) < block_size) lg++;
     dst[5] = lg;
+    dst[6] = checksum_enabled ? 0x80 : 0; /* HAS_CHECKSUM | algo 0 (rapidhash) */
     const uint16_t crc = hdr_hash16(dst);
     dst[14] = (uint8_t)crc;
     dst[15] = (uint8_t)(crc >> 8);
@@ -319,6 +324,7 @@ int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const 
     if (nb64 > 0x7FFFFFFFull) return ZXC_ERROR_BAD_BLOCK_SIZE;
     const uint32_t nb = (uint32_t)nb64;
     uint32_t* sizes = NULL;
+    uint32_t global_hash = 0;
     if (nb > 0) {
         if (zxc_mi355x_device_count() <= 0) return ZXC_ERROR_GPU_UNAVAILABLE;
         const uint32_t stride = zxc_mi355x_encode_slot_stride((uint32_t)block_size);
@@ -333,8 +339,8 @@ int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const 
         if (sizes && offs && d_src && d_slots && d_sizes && d_offs) {
             rc = zxc_mi355x_memcpy_h2d(d_src, src, src_size);
             if (rc == ZXC_OK)
-                rc = zxc_mi355x_encode_blocks_device(d_src, src_size, (uint32_t)block_size, level, d_slots,
-                                                     (uint32_t*)d_sizes, NULL);
+                rc = zxc_mi355x_encode_blocks_device(d_src, src_size, (uint32_t)block_size, level, checksum_enabled,
+                                                     d_slots, (uint32_t*)d_sizes, NULL);
             if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(NULL);
             if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(sizes, d_sizes, (size_t)nb * 4);
             uint64_t total = 0;
@@ -353,6 +359,9 @@ int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const 
                                                      (const uint64_t*)d_offs, d_out, nb, NULL);
             if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(NULL);
             if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(dst + op, d_out, (size_t)total);
+            if (rc == ZXC_OK && checksum_enabled) /* fold the block trailers in stream order (zxc_dispatch.c:754-759) */
+                for (uint32_t i = 0; i < nb; i++)
+                    global_hash = ((global_hash << 1) | (global_hash >> 31)) ^ rd32(dst + op + offs[i] + sizes[i] - 4);
             if (rc == ZXC_OK) op += (size_t)total;
         }
         zxc_mi355x_free(d_src);
@@ -377,7 +386,7 @@ int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const 
     free(sizes);
     if (dst_capacity - op < ZXC_FILE_FOOTER_SIZE) return ZXC_ERROR_DST_TOO_SMALL;
     wr64(dst + op, (uint64_t)src_size);
-    wr32(dst + op + 8, 0); /* global hash: zero when checksums are off */
+    wr32(dst + op + 8, checksum_enabled ? global_hash : 0); /* zero when checksums are off */
     op += ZXC_FILE_FOOTER_SIZE;
     return (int64_t)op;
 }
