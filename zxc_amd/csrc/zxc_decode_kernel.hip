@@ -526,12 +526,29 @@ __device__ int run_sequences(const LzStreams& S, uint8_t* __restrict__ dst, uint
             const uint32_t qb = (qa + ml < M) ? qa + ml : M;
             bool pending = mine && ml != 0u && !(S.dbg & DBG_NO_MATCH);
             uint64_t need = 0;
+            uint32_t qsrc = qa;  // where the copy reads from (qa unless redirected)
             {
                 // all lanes run the same bpermute sequence; only lanes reaching into the batch use it
                 const uint32_t ja = lanes_le(Es, qa);                    // first lane with E > qa
                 const uint32_t jbp = lanes_le(Ms, qb ? qb - 1u : 0u);    // number of lanes with M < qb
                 if (pending && qb > p && jbp > ja && !(S.dbg & DBG_NO_DEPS))
                     need = ((jbp >= 64u) ? ~0ull : ((1ull << jbp) - 1ull)) & ~((1ull << ja) - 1ull);
+                // Redirect: when my whole source sits inside ONE earlier match j of this batch (within
+                // its first period) and j has no pending dependency itself, my bytes equal j's source
+                // bytes at the same displacement: read those instead and drop the dependency. Three
+                // passes collapse chains of such containments (each pass resolves one more level).
+                const int jl = (int)(ja & 63u);
+                const uint32_t jM = __shfl(M, jl), jE = __shfl(E, jl), jo = __shfl(off, jl);
+                const bool simple = need != 0ull && jbp == ja + 1u && off >= ml && qa >= jM && qb <= jE && qb - jM <= jo;
+#pragma unroll
+                for (int pass = 0; pass < 3; pass++) {
+                    const uint32_t jready = __shfl((uint32_t)(need == 0ull), jl);
+                    const uint32_t jq = __shfl(qsrc, jl);
+                    if (simple && need != 0ull && jready) {
+                        qsrc = jq + (qa - jM);
+                        need = 0;
+                    }
+                }
             }
             const bool overlap = off < ml;
             // lane-per-sequence in 32-byte steps works whenever a step's source is complete before
@@ -554,7 +571,7 @@ __device__ int run_sequences(const LzStreams& S, uint8_t* __restrict__ dst, uint
                         const bool act = sa && so < ml;
                         if (__ballot(act) == 0ull) break;
                         const uint32_t n = (ml - so < SHORT_MAX) ? ml - so : SHORT_MAX;
-                        const uint32_t q = qa + so, d = M + so;
+                        const uint32_t q = qsrc + so, d = M + so;
                         const bool isfar = act && q < ring_lo;
                         const uint32_t ts = put_tail_index(d, n);
                         v4u s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
