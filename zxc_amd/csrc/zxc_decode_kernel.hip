@@ -64,6 +64,7 @@ struct __attribute__((aligned(16))) WaveLds {
     uint32_t ring[RING_WORDS];          // last 16 KiB of output, position p at byte p & RING_MASK
     uint32_t vval[128];                 // values of the batch's varints, in stream order
     uint32_t vpos[130];                 // their byte positions in the extras stream (+ end cursor)
+    uint32_t trash[64];                 // per-lane sink for predicated-off stores (cheaper than exec juggling)
 };
 
 // ---------------------------------------------------------------- small helpers
@@ -141,24 +142,29 @@ __device__ __forceinline__ void ring_put(WaveLds& L, uint32_t d, uint32_t n, con
     const uint32_t a = d & 3u;
     uint32_t hl = a ? 4u - a : 0u;
     if (hl > n) hl = n;
+    if (!act) { hl = 0; n = 0; }
     const uint32_t rem = n - hl;
     const uint32_t ts = hl + (rem & ~3u);
     const uint32_t tl = rem & 3u;
     const uint32_t sh = (4u - a) & 3u;
-    const uint32_t e = a + n;  // end of the run on the destination dword grid
-    uint8_t* const r8 = (uint8_t*)L.ring;
+    const uint32_t e = act ? a + n : 0u;  // end of the run on the destination dword grid
+    uint8_t* const l8 = (uint8_t*)&L;     // ring bytes first, then the other members
+    const uint32_t trash8 = (uint32_t)__builtin_offsetof(WaveLds, trash) + 4u * (uint32_t)(threadIdx.x & 63u);
+    // Stores are unconditional: a lane with nothing to store at a slot aims at its private trash
+    // dword instead (one v_cndmask on the address; no exec save/restore per store).
 #pragma unroll
     for (int b = 0; b < 3; b++)  // head bytes (only when d is not dword aligned)
-        if (act && (uint32_t)b < hl) r8[(d + b) & RING_MASK] = (uint8_t)(s[0] >> (8 * b));
+        l8[((uint32_t)b < hl) ? ((d + b) & RING_MASK) : trash8] = (uint8_t)(s[0] >> (8 * b));
 #pragma unroll
-    for (int j = 0; j <= NW; j++) {  // destination dword j covers grid bytes [4j, 4j+4)
-        const uint32_t hi = j < NW ? s[j] : 0u, lo = j > 0 ? s[j - 1] : 0u;
+    for (int j = 0; j < NW; j++) {  // destination dword j covers grid bytes [4j, 4j+4)
+        const uint32_t hi = s[j], lo = j > 0 ? s[j - 1] : 0u;
         const uint32_t t = a ? __builtin_amdgcn_alignbyte(hi, lo, sh) : hi;
-        if (act && 4u * j >= a && 4u * j + 4u <= e) L.ring[((d - a + 4u * j) & RING_MASK) >> 2] = t;
+        const bool w = 4u * j >= a && 4u * j + 4u <= e;
+        *(uint32_t*)(l8 + (w ? ((d - a + 4u * j) & RING_MASK) : trash8)) = t;
     }
 #pragma unroll
     for (int b = 0; b < 3; b++)  // tail bytes
-        if (act && (uint32_t)b < tl) r8[(d + ts + b) & RING_MASK] = (uint8_t)(tailw >> (8 * b));
+        l8[((uint32_t)b < tl) ? ((d + ts + b) & RING_MASK) : trash8] = (uint8_t)(tailw >> (8 * b));
 }
 
 // Per-block view shared by the copy routines.
