@@ -64,6 +64,15 @@ ZXC_EXPORT int zxc_mi355x_decode_blocks_device(const void* d_comp, const zxc_dev
                                                uint32_t n_jobs, void* d_out, int32_t* d_status,
                                                uint32_t block_size, int verify_trailer, void* stream);
 
+/* Same, for archives compressed with a dictionary: d_dict[0..dict_size) is logically prepended to
+ * every block (reference d_floor = dst - dict_size, src/lib/zxc_decompress.c:1028); d_dict_huf is
+ * the dictionary's 128-byte shared literal table (enc_lit = 3 sections) or NULL. */
+ZXC_EXPORT int zxc_mi355x_decode_blocks_dict_device(const void* d_comp, const zxc_dev_job_t* d_jobs,
+                                                    uint32_t n_jobs, void* d_out, int32_t* d_status,
+                                                    uint32_t block_size, int verify_trailer,
+                                                    const void* d_dict, uint32_t dict_size,
+                                                    const void* d_dict_huf, void* stream);
+
 /* ---- encode side (LZ77 match finder + GLO serialiser, zxc_amd/csrc/zxc_encode_kernel.hip) ----
  * Replaces the per-block calls to zxc_compress_chunk_wrapper (src/lib/zxc_compress.c:2041-2074)
  * made by zxc_compress (src/lib/zxc_dispatch.c:734-780). Block i of the source

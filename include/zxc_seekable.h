@@ -41,6 +41,10 @@ ZXC_EXPORT int64_t zxc_seekable_decompress_range_mt(zxc_seekable* s, void* dst, 
 /* reference include/zxc_seekable.h:226 */
 ZXC_EXPORT void zxc_seekable_free(zxc_seekable* s);
 
+/* reference include/zxc_seekable.h:243 (impl src/lib/zxc_seekable.c:1144-1174): dictionary for a
+ * dict-compressed archive; content (and optional 128-byte shared table) are copied. */
+ZXC_EXPORT int zxc_seekable_set_dict(zxc_seekable* s, const void* dict, size_t dict_size, const void* dict_huf);
+
 /* reference include/zxc_seekable.h:263-272 (impl src/lib/zxc_seekable.c:172-214) */
 ZXC_EXPORT int64_t zxc_write_seek_table(uint8_t* dst, const size_t dst_capacity,
                                         const uint32_t* comp_sizes, const uint32_t num_blocks);

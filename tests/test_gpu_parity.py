@@ -8,7 +8,7 @@ import random
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, read
+from conftest import GOLDEN, load_dict, read
 
 pytestmark = pytest.mark.gpu
 
@@ -32,11 +32,20 @@ def gpu(product):
 def test_conformance_valid(gpu, oracle, name):
     comp = read(f"conformance/valid/{name}.zxc")
     exp = read(f"conformance/valid/{name}.expected")
-    rc, out = gpu.decompress(comp, len(exp), checksum=True, raise_on_error=False)
+    d = dh = None
     if name.startswith("dict_"):
-        assert rc in (-15, UNSUPPORTED)  # dictionary archives: next scope row, must not decode silently
-        return
+        assert gpu.decompress(comp, len(exp), raise_on_error=False)[0] == -15  # ZXC_ERROR_DICT_REQUIRED without it
+        zxd = "dict_http.zxd" if name.startswith("dict_http") else "dict_text.zxd"
+        d, dh = load_dict(os.path.join(GOLDEN, "conformance", "valid", zxd))
+        assert gpu.decompress(comp, len(exp), raise_on_error=False, dict_=d[:-1] + b"?", dict_huf=dh)[0] == -16  # mismatch
+    rc, out = gpu.decompress(comp, len(exp), checksum=True, raise_on_error=False, dict_=d, dict_huf=dh)
     assert rc == len(exp) and out == exp
+    if name == "dict_seekable_l7":
+        s = gpu.Seekable(comp)
+        assert s.decompress_range(0, 10, raise_on_error=False)[0] == -15
+        assert s.set_dict(d, dh) == 0
+        assert s.decompress_range(0, len(exp)) == exp
+        assert s.decompress_range(len(exp) // 3, len(exp) // 2) == exp[len(exp) // 3: len(exp) // 3 + len(exp) // 2]
 
 
 def test_conformance_invalid(gpu, manifest):
@@ -51,7 +60,7 @@ def test_format_golden(gpu, manifest):
             continue
         rc, out = gpu.decompress(read(f"format/{f}"), meta["decoded_size"], raise_on_error=False)
         if f in ("09_block_dict.zxc", "12_glo_huffman_dict.zxc"):
-            assert rc in (-15, UNSUPPORTED)  # dictionary archives: next scope row
+            assert rc == -15  # needs the generator's dictionary (reference tests/format); rejected loudly
             continue
         assert rc == meta["decoded_size"], f
         assert hashlib.sha256(out).hexdigest() == meta["decoded_sha256"], f

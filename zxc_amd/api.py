@@ -75,6 +75,8 @@ def lib():
         L.zxc_seekable_decompress_range_mt.restype = C.c_int64
         L.zxc_seekable_decompress_range_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64,
                                                        C.c_size_t, C.c_int]
+        L.zxc_seekable_set_dict.restype = C.c_int
+        L.zxc_seekable_set_dict.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p]
         L.zxc_mi355x_device_count.restype = C.c_int
         L.zxc_mi355x_set_device.argtypes = [C.c_int]
         L.zxc_mi355x_plan_seekable.restype = C.c_int64
@@ -110,11 +112,16 @@ def compress(data: bytes, level=3, block_size=65536, seekable=True, checksum=Fal
     return out.raw[:rc] if raise_on_error else (rc, out.raw[:rc])
 
 
-def decompress(comp: bytes, capacity=None, checksum=False, raise_on_error=True):
+def decompress(comp: bytes, capacity=None, checksum=False, raise_on_error=True, dict_=None, dict_huf=None):
     """zxc_decompress(): whole frame, host buffers in, host buffer out (blocks decode on the GPU)."""
     cap = get_decompressed_size(comp) if capacity is None else int(capacity)
     out = C.create_string_buffer(max(cap, 1))
     o = _DecompressOpts(checksum_enabled=int(checksum))
+    if dict_:
+        _keep = (C.create_string_buffer(dict_, len(dict_)), C.create_string_buffer(dict_huf, 128) if dict_huf else None)
+        o.dict = C.cast(_keep[0], C.c_void_p)
+        o.dict_size = len(dict_)
+        o.dict_huf = C.cast(_keep[1], C.c_void_p) if dict_huf else None
     rc = lib().zxc_decompress(comp, len(comp), out if cap else None, cap, C.byref(o))
     if rc < 0:
         if raise_on_error:
@@ -152,6 +159,9 @@ class Seekable:
 
     def block_decomp_size(self, i):
         return int(lib().zxc_seekable_get_block_decomp_size(self._h, i))
+
+    def set_dict(self, dict_, dict_huf=None):
+        return int(lib().zxc_seekable_set_dict(self._h, dict_, len(dict_), dict_huf))
 
     def decompress_range(self, offset, length, n_threads=None, raise_on_error=True):
         out = C.create_string_buffer(max(length, 1))

@@ -174,6 +174,8 @@ struct Out {
     uint32_t out_pad;    // out_len rounded up to 16 (readable/writable)
     uint32_t flushed;    // output positions below this are in global memory (multiple of 16)
     uint32_t dbg;
+    const uint8_t* dict; // dictionary prefix: logically occupies output positions [-dict_size, 0)
+    uint32_t dict_size;
 };
 
 // Already-final output at position q that has left the ring: read it back from the
@@ -195,6 +197,14 @@ __device__ __forceinline__ v4u far_rd128(const Out& O, uint32_t q) {
 __device__ __forceinline__ uint32_t far_rd8(const Out& O, uint32_t q) {
     if ((O.dbg & DBG_NO_FAR) || q >= O.out_pad) return 0;
     return __builtin_nontemporal_load(O.dst + q);
+}
+
+// One source byte at output position s, where a negative s (as int32) addresses the dictionary
+// prefix that logically precedes the block (reference: d_floor = dst - dict_size,
+// src/lib/zxc_decompress.c:1028).
+__device__ __forceinline__ uint32_t src_rd8(WaveLds& L, const Out& O, uint32_t s, uint32_t ring_lo) {
+    if ((int32_t)s < 0) return ld8(O.dict + (int32_t)(O.dict_size + s));
+    return s >= ring_lo ? ring_rd8(L, s) : far_rd8(O, s);
 }
 
 // Stream finished output from the ring to HBM: chunks [O.flushed, upto & ~15).
@@ -222,7 +232,7 @@ __device__ void coop_copy(WaveLds& L, const Out& O, uint32_t dpos, uint32_t spos
     const uint32_t h = h0 < n ? h0 : n;  // bytes up to the first 16-byte boundary
     if ((uint32_t)lane < h) {
         const uint32_t s = spos + lane;
-        const uint32_t b = lit ? ld8(lit + lane) : (s >= ring_lo ? ring_rd8(L, s) : far_rd8(O, s));
+        const uint32_t b = lit ? ld8(lit + lane) : src_rd8(L, O, s, ring_lo);
         ring_wr8(L, dpos + lane, b);
     }
     const uint32_t nb = (n - h) >> 4;
@@ -231,7 +241,11 @@ __device__ void coop_copy(WaveLds& L, const Out& O, uint32_t dpos, uint32_t spos
         const uint32_t s = spos + o;
         v4u v;
         if (lit) v = ld128(lit + o);
-        else if (s >= ring_lo) v = ring_rd128(L, s);
+        else if ((int32_t)s < 0) {  // (partly) inside the dictionary: byte gather (rare)
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (uint32_t k = 0; k < 16u; k++) w[k >> 2] |= src_rd8(L, O, s + k, ring_lo) << (8u * (k & 3u));
+            v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+        } else if (s >= ring_lo) v = ring_rd128(L, s);
         else v = far_rd128(O, s);
         ring_wr128_aligned(L, dpos + o, v);
     }
@@ -239,7 +253,7 @@ __device__ void coop_copy(WaveLds& L, const Out& O, uint32_t dpos, uint32_t spos
     if ((uint32_t)lane < tl) {
         const uint32_t o = n - tl + lane;
         const uint32_t s = spos + o;
-        const uint32_t b = lit ? ld8(lit + o) : (s >= ring_lo ? ring_rd8(L, s) : far_rd8(O, s));
+        const uint32_t b = lit ? ld8(lit + o) : src_rd8(L, O, s, ring_lo);
         ring_wr8(L, dpos + o, b);
     }
     wave_lds_fence();
@@ -372,6 +386,8 @@ struct LzStreams {
     uint32_t off8;        // GLO 1-byte offsets
     uint32_t ghi;
     uint32_t dbg;         // ablation switches
+    const uint8_t* dict;  // dictionary prefix (or nullptr)
+    uint32_t dict_size;
 };
 
 // number of lanes whose (ascending over lanes) value is <= x: binary search by bpermute
@@ -387,7 +403,7 @@ __device__ __forceinline__ uint32_t lanes_le(uint32_t sorted, uint32_t x) {
 }
 
 // Executes all sequences of one block. Returns decoded size or a negative error.
-__device__ int run_sequences(const LzStreams& S, uint8_t* __restrict__ dst, uint32_t out_len, uint32_t cap,
+__device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __restrict__ dst, uint32_t out_len, uint32_t cap,
                              WaveLds& L, int lane) {
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const uint32_t n_total = S.n_seq + 1u;  // + pseudo sequence carrying the trailing literals
@@ -397,6 +413,8 @@ __device__ int run_sequences(const LzStreams& S, uint8_t* __restrict__ dst, uint
     O.out_pad = (out_len + 15u) & ~15u;
     O.flushed = 0;
     O.dbg = S.dbg;
+    O.dict = S.dict;
+    O.dict_size = S.dict_size;
     uint32_t p = 0, lp = 0, cur = 0, dead = 0, seq_base = 0;
 
     while (seq_base < n_total) {
@@ -458,7 +476,7 @@ __device__ int run_sequences(const LzStreams& S, uint8_t* __restrict__ dst, uint
         int err = 0;
         if (real) {
             if (est > cap || len > cap - est || lst > S.n_lit || ll > S.n_lit - lst) err = E_OVERFLOW;
-            else if (off > est + ll) err = E_BAD_OFFSET;
+            else if (off > est + ll + S.dict_size) err = E_BAD_OFFSET;
         } else if (valid) {  // pseudo sequence: whatever literals are left
             if (est > cap || lst > S.n_lit || S.n_lit - lst > cap - est) err = E_OVERFLOW;
             else { ll = S.n_lit - lst; len = ll; }
@@ -528,14 +546,16 @@ __device__ int run_sequences(const LzStreams& S, uint8_t* __restrict__ dst, uint
             // ---- matches. Sequence i may only copy once every earlier match of this batch
             // that overlaps its source [qa, qb) is finished: those are lanes ja..jb.
             const uint32_t Es = mine ? E : 0xFFFFFFFFu, Ms = mine ? M : 0xFFFFFFFFu;
-            const uint32_t qa = M - off;
-            const uint32_t qb = (qa + ml < M) ? qa + ml : M;
+            const bool fromdict = off > M;  // source starts inside the dictionary prefix
+            const uint32_t qa = M - off;    // (wraps negative then; only src_rd8 / coop paths read it)
+            const uint32_t qb = fromdict ? ((off - M < ml) ? ((ml - (off - M) < M) ? ml - (off - M) : M) : 0u)
+                                         : ((qa + ml < M) ? qa + ml : M);
             bool pending = mine && ml != 0u && !(S.dbg & DBG_NO_MATCH);
             uint64_t need = 0;
             uint32_t qsrc = qa;  // where the copy reads from (qa unless redirected)
             {
                 // all lanes run the same bpermute sequence; only lanes reaching into the batch use it
-                const uint32_t ja = lanes_le(Es, qa);                    // first lane with E > qa
+                const uint32_t ja = lanes_le(Es, fromdict ? 0u : qa);     // first lane with E > qa
                 const uint32_t jbp = lanes_le(Ms, qb ? qb - 1u : 0u);    // number of lanes with M < qb
                 if (pending && qb > p && jbp > ja && !(S.dbg & DBG_NO_DEPS))
                     need = ((jbp >= 64u) ? ~0ull : ((1ull << jbp) - 1ull)) & ~((1ull << ja) - 1ull);
@@ -545,13 +565,14 @@ __device__ int run_sequences(const LzStreams& S, uint8_t* __restrict__ dst, uint
                 // passes collapse chains of such containments (each pass resolves one more level).
                 const int jl = (int)(ja & 63u);
                 const uint32_t jM = __shfl(M, jl), jE = __shfl(E, jl), jo = __shfl(off, jl);
-                const bool simple = need != 0ull && jbp == ja + 1u && off >= ml && qa >= jM && qb <= jE && qb - jM <= jo;
+                const bool simple = need != 0ull && !fromdict && jbp == ja + 1u && off >= ml && qa >= jM && qb <= jE && qb - jM <= jo;
 #pragma unroll
                 for (int pass = 0; pass < 3; pass++) {
                     const uint32_t jready = __shfl((uint32_t)(need == 0ull), jl);
                     const uint32_t jq = __shfl(qsrc, jl);
-                    if (simple && need != 0ull && jready) {
-                        qsrc = jq + (qa - jM);
+                    const uint32_t nq = jq + (qa - jM);
+                    if (simple && need != 0ull && jready && (int32_t)nq >= 0) {  // not into the dictionary prefix
+                        qsrc = nq;
                         need = 0;
                     }
                 }
@@ -559,8 +580,8 @@ __device__ int run_sequences(const LzStreams& S, uint8_t* __restrict__ dst, uint
             const bool overlap = off < ml;
             // lane-per-sequence in 32-byte steps works whenever a step's source is complete before
             // the step runs: no overlap at all, or a period of at least one step.
-            const bool stepable = ml <= MED_MAX && (!overlap || off >= SHORT_MAX);
-            const bool bytewise = overlap && off < SHORT_MAX && ml <= SHORT_MAX;
+            const bool stepable = !fromdict && ml <= MED_MAX && (!overlap || off >= SHORT_MAX);
+            const bool bytewise = !fromdict && overlap && off < SHORT_MAX && ml <= SHORT_MAX;
             const bool is_long = !stepable && !bytewise;
             bool far_waited = false;
             for (uint32_t round = 0;; round++) {
@@ -667,7 +688,7 @@ struct ScratchPool {
     uint32_t n_slots;
     int held;  // slot index or -1
 };
-__device__ uint8_t* scratch_acquire(ScratchPool& sp, int lane) {
+__device__ __forceinline__ uint8_t* scratch_acquire(ScratchPool& sp, int lane) {
     if (sp.held < 0) {
         uint32_t got = 0;
         if (lane == 0) {
@@ -682,7 +703,7 @@ __device__ uint8_t* scratch_acquire(ScratchPool& sp, int lane) {
     }
     return sp.base + (size_t)sp.held * sp.stride;
 }
-__device__ void scratch_release(ScratchPool& sp, int lane) {
+__device__ __forceinline__ void scratch_release(ScratchPool& sp, int lane) {
     if (sp.held >= 0) {
         __builtin_amdgcn_s_waitcnt(0);
         if (lane == 0) __hip_atomic_store(sp.busy + sp.held, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -757,12 +778,14 @@ __device__ int rle_expand(const uint8_t* __restrict__ r, uint32_t rsize, uint8_t
     return rc;
 }
 
-__device__ int decode_lz_block(const uint8_t* data, uint32_t comp_sz, bool ghi, uint8_t* dst, uint32_t out_len,
+__device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t comp_sz, bool ghi, uint8_t* dst, uint32_t out_len,
                                uint32_t cap, uint32_t block_size, ScratchPool& pool, WaveLds& L, int lane,
-                               uint32_t dbg) {
+                               uint32_t dbg, const uint8_t* dict, uint32_t dict_size, const uint8_t* dict_huf) {
     if (comp_sz < 12u) return E_BAD_HEADER;
     LzStreams S;
     S.dbg = dbg;
+    S.dict = dict;
+    S.dict_size = dict_size;
     S.n_seq = uni(ld32(data));
     S.n_lit = uni(ld32(data + 4));
     const uint32_t enc_lit = uni(ld8(data + 8)), enc_tok = uni(ld8(data + 9)), enc_off = uni(ld8(data + 11));
@@ -794,11 +817,11 @@ __device__ int decode_lz_block(const uint8_t* data, uint32_t comp_sz, bool ghi, 
         if (lit_comp > avail) return E_CORRUPT;
         if (S.n_lit != 0u) {
             if (S.n_lit > cap) return E_DST_TOO_SMALL;
-            if (enc_lit == 3u) return E_DICT_REQUIRED;  // shared-table sections need a dictionary (next scope row)
+            if (enc_lit == 3u && !dict_huf) return E_DICT_REQUIRED;  // shared table comes with the dictionary
             if (S.n_lit > block_size) return E_CORRUPT;
             uint8_t* scratch = scratch_acquire(pool, lane);
             const int rc = pivco_decode(pdata, lit_comp, scratch, S.n_lit, scratch + block_size + 64u,
-                                        reinterpret_cast<PivLds&>(L), lane);
+                                  reinterpret_cast<PivLds&>(L), lane, enc_lit == 3u ? dict_huf : nullptr);
             if (rc != 0) return rc;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // literals are read back with L1-cached loads
@@ -825,7 +848,7 @@ __device__ int decode_lz_block(const uint8_t* data, uint32_t comp_sz, bool ghi, 
         uint8_t* scratch = scratch_acquire(pool, lane);
         uint8_t* tokbuf = scratch + 2u * (block_size + 64u);
         const int rc = pivco_decode(S.tok, tok_comp, tokbuf, S.n_seq, scratch + block_size + 64u,
-                                    reinterpret_cast<PivLds&>(L), lane);
+                                    reinterpret_cast<PivLds&>(L), lane, nullptr);
         if (rc != 0) return rc;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -847,7 +870,8 @@ extern "C" __global__ void __launch_bounds__(64, WAVES_PER_SIMD)
 zxc_decode_blocks_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
                          uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,
                          uint32_t trailer_bytes, uint8_t* __restrict__ scratch, uint32_t scratch_stride, uint32_t dbg,
-                         uint32_t* __restrict__ slot_busy, uint32_t n_slots) {
+                         uint32_t* __restrict__ slot_busy, uint32_t n_slots, const uint8_t* __restrict__ dict,
+                         uint32_t dict_size, const uint8_t* __restrict__ dict_huf) {
     // One workgroup (= one wavefront) per block: the hardware dispatcher hands out blocks as
     // wave slots free up, which is all the dynamic scheduling RAW-vs-dense blocks need.
     __shared__ union { WaveLds w; PivLds p; } lds;  // the PivCo tables reuse the ring's LDS (never live together)
@@ -873,7 +897,8 @@ zxc_decode_blocks_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* 
         } else if (trailer_bytes && wave_checksum32(src + 8, comp_sz, lane) != uni(ld32(src + 8 + comp_sz))) {
             rc = E_BAD_CHECKSUM;  // per-block checksum of the compressed payload (zxc_decompress.c:1662-1666)
         } else if (type == 1u || type == 2u) {
-            rc = decode_lz_block(src + 8, comp_sz, type == 2u, dst, out_len, cap, block_size, pool, L, lane, dbg);
+            rc = decode_lz_block(src + 8, comp_sz, type == 2u, dst, out_len, cap, block_size, pool, L, lane, dbg, dict,
+                                 dict_size, dict_huf);
             scratch_release(pool, lane);
         } else if (type == 0u) {  // RAW: stored bytes
             if (comp_sz > cap) rc = E_DST_TOO_SMALL;

@@ -11,7 +11,8 @@
 extern "C" __global__ void zxc_decode_blocks_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                     uint8_t* out, int32_t* status, uint32_t block_size,
                                                     uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride, uint32_t dbg,
-                                                    uint32_t* slot_busy, uint32_t n_slots);
+                                                    uint32_t* slot_busy, uint32_t n_slots, const uint8_t* dict,
+                                                    uint32_t dict_size, const uint8_t* dict_huf);
 
 extern "C" __global__ void zxc_encode_blocks_kernel(const uint8_t* src, uint64_t src_size, uint32_t block_size, uint8_t* slots,
                                                     uint32_t slot_stride, uint32_t* sizes, uint32_t n_blocks, uint32_t with_checksum);
@@ -76,8 +77,9 @@ int zxc_mi355x_synchronize(void* stream) {
     return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
 }
 
-int zxc_mi355x_decode_blocks_device(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32_t n_jobs, void* d_out,
-                                    int32_t* d_status, uint32_t block_size, int verify_trailer, void* stream) {
+static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32_t n_jobs, void* d_out,
+                         int32_t* d_status, uint32_t block_size, int verify_trailer, void* stream, const void* d_dict,
+                         uint32_t dict_size, const void* d_dict_huf) {
     if (n_jobs == 0) return ZXC_OK;
     if (!d_comp || !d_jobs || !d_out || !d_status) return ZXC_ERROR_NULL_INPUT;
     if (block_size < (1u << 12) || block_size > (1u << 21) || (block_size & (block_size - 1u))) return ZXC_ERROR_BAD_BLOCK_SIZE;
@@ -96,9 +98,14 @@ int zxc_mi355x_decode_blocks_device(const void* d_comp, const zxc_dev_job_t* d_j
         if (nb > 32) nb = 32;
         g_dev[dev].wg_per_cu = nb;
     }
-    const uint32_t n_slots = (uint32_t)g_dev[dev].cus * (uint32_t)g_dev[dev].wg_per_cu;
     // scratch slot: [expanded literals | PivCo ping-pong | decoded tokens]
     const uint32_t stride = (2u * (block_size + 64u) + block_size / 5u + 16u + 64u + 255u) & ~255u;
+    // Only blocks with an RLE / PivCo section take a slot, waiters spin and holders never wait, so
+    // the pool may be smaller than the resident workgroup count: cap it at 1 GiB of scratch.
+    const uint32_t max_slots = (uint32_t)g_dev[dev].cus * (uint32_t)g_dev[dev].wg_per_cu;  // <= 8192
+    uint32_t n_slots = (uint32_t)(((size_t)1 << 30) / stride);
+    if (n_slots > max_slots) n_slots = max_slots;
+    if (n_slots < 64u) n_slots = 64u;
     const size_t need = (size_t)n_slots * stride;
     if (g_dev[dev].bytes < need) {
         if (g_dev[dev].scratch) (void)hipFree(g_dev[dev].scratch);
@@ -108,13 +115,27 @@ int zxc_mi355x_decode_blocks_device(const void* d_comp, const zxc_dev_job_t* d_j
         g_dev[dev].bytes = need;
     }
     if (!g_dev[dev].counter) {  // slot-busy flags, zero = free; every workgroup releases what it took
-        if (hipMalloc((void**)&g_dev[dev].counter, (size_t)n_slots * 4u) != hipSuccess) return ZXC_ERROR_MEMORY;
-        if (hipMemset(g_dev[dev].counter, 0, (size_t)n_slots * 4u) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
+        if (hipMalloc((void**)&g_dev[dev].counter, (size_t)8192 * 4u) != hipSuccess) return ZXC_ERROR_MEMORY;
+        if (hipMemset(g_dev[dev].counter, 0, (size_t)8192 * 4u) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
     }
     hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
                        d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, verify_trailer ? 4u : 0u,
-                       g_dev[dev].scratch, stride, g_debug_flags, g_dev[dev].counter, n_slots);
+                       g_dev[dev].scratch, stride, g_debug_flags, g_dev[dev].counter, n_slots, (const uint8_t*)d_dict,
+                       dict_size, (const uint8_t*)d_dict_huf);
     return hipGetLastError() == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
+}
+
+int zxc_mi355x_decode_blocks_device(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32_t n_jobs, void* d_out,
+                                    int32_t* d_status, uint32_t block_size, int verify_trailer, void* stream) {
+    return decode_launch(d_comp, d_jobs, n_jobs, d_out, d_status, block_size, verify_trailer, stream, NULL, 0, NULL);
+}
+
+int zxc_mi355x_decode_blocks_dict_device(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32_t n_jobs, void* d_out,
+                                         int32_t* d_status, uint32_t block_size, int verify_trailer, const void* d_dict,
+                                         uint32_t dict_size, const void* d_dict_huf, void* stream) {
+    if (dict_size > 65535u || (dict_size && !d_dict)) return ZXC_ERROR_DICT_TOO_LARGE;
+    return decode_launch(d_comp, d_jobs, n_jobs, d_out, d_status, block_size, verify_trailer, stream, d_dict, dict_size,
+                         d_dict_huf);
 }
 
 uint32_t zxc_mi355x_encode_slot_stride(uint32_t block_size) { return 2u * block_size + 512u; }

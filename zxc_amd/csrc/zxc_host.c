@@ -94,6 +94,62 @@ uint64_t zxc_compress_bound(const size_t input_size) {
     return ZXC_FILE_HEADER_SIZE + n * (8 + 4 + 68) + (uint64_t)input_size + 8 + 8 + n * 4 + ZXC_FILE_FOOTER_SIZE;
 }
 
+/* ------------------------------------------------- dictionary id (host side) */
+/* zxc_dict_id (src/lib/zxc_dict.c:35-45) = rapidhash v3 of the content folded to 32 bits, chained
+ * over the 128-byte shared table when there is one. rapidhash restated from its published
+ * algorithm (the reference vendors it under src/lib/vendors/rapidhash.h). Header-level work: it
+ * decides DICT_MISMATCH before anything is sent to the GPU. */
+static const uint64_t RH_S[8] = {0x2d358dccaa6c78a5ull, 0x8bb84b93962eacc9ull, 0x4b33a62ed433d4a3ull,
+                                 0x4d5a2da51de1aa47ull, 0xa0761d6478bd642full, 0xe7037ed1a0b428dbull,
+                                 0x90ed1765281c388cull, 0xaaaaaaaaaaaaaaaaull};
+static uint64_t rh_mix(uint64_t a, uint64_t b) {
+    const __uint128_t r = (__uint128_t)a * b;
+    return (uint64_t)r ^ (uint64_t)(r >> 64);
+}
+static uint64_t host_rapidhash(const uint8_t* p, size_t len, uint64_t seed) {
+    uint64_t a = 0, b = 0;
+    size_t i = len;
+    seed ^= rh_mix(seed ^ RH_S[2], RH_S[1]);
+    if (len <= 16) {
+        if (len >= 4) {
+            seed ^= len;
+            if (len >= 8) { a = rd64(p); b = rd64(p + len - 8); }
+            else { a = rd32(p); b = rd32(p + len - 4); }
+        } else if (len > 0) {
+            a = ((uint64_t)p[0] << 45) | p[len - 1];
+            b = p[len >> 1];
+        }
+    } else {
+        if (len > 112) {
+            uint64_t s[7];
+            for (int k = 0; k < 7; k++) s[k] = seed;
+            do {
+                for (int k = 0; k < 7; k++) s[k] = rh_mix(rd64(p + 16 * k) ^ RH_S[k], rd64(p + 16 * k + 8) ^ s[k]);
+                p += 112;
+                i -= 112;
+            } while (i > 112);
+            seed = s[0] ^ s[1] ^ s[2] ^ s[3] ^ s[4] ^ s[5] ^ s[6];
+        }
+        static const int sel[6] = {2, 2, 1, 1, 2, 1};
+        for (int k = 0; k < 6 && i > (size_t)(16 * (k + 1)); k++)
+            seed = rh_mix(rd64(p + 16 * k) ^ RH_S[sel[k]], rd64(p + 16 * k + 8) ^ seed);
+        a = rd64(p + i - 16) ^ i;
+        b = rd64(p + i - 8);
+    }
+    a ^= RH_S[1];
+    b ^= seed;
+    const __uint128_t r = (__uint128_t)a * b;
+    return rh_mix((uint64_t)r ^ RH_S[7], (uint64_t)(r >> 64) ^ RH_S[1] ^ i);
+}
+static uint32_t dict_id_of(const uint8_t* dict, size_t n, const uint8_t* huf) {
+    if (!dict || n == 0) return 0;
+    uint64_t h = host_rapidhash(dict, n, 0);
+    const uint32_t base = (uint32_t)(h ^ (h >> 32));
+    if (!huf) return base;
+    h = host_rapidhash(huf, ZXC_HUF_TABLE_SIZE, base);
+    return (uint32_t)(h ^ (h >> 32));
+}
+
 /* ------------------------------------------------------------- containers */
 static int read_file_header(const uint8_t* src, size_t n, uint32_t* block_size, int* has_checksum,
                             uint32_t* dict_id) {
@@ -143,19 +199,27 @@ typedef struct {
     void* d_jobs;
     void* d_out;
     void* d_status;
+    void* d_dict; /* [dict content | 128-byte shared table] or NULL */
 } dev_bufs_t;
+
+typedef struct {
+    const uint8_t* dict;
+    size_t dict_size;
+    const uint8_t* dict_huf;
+} dict_ref_t;
 
 static void dev_bufs_free(dev_bufs_t* b) {
     zxc_mi355x_free(b->d_comp);
     zxc_mi355x_free(b->d_jobs);
     zxc_mi355x_free(b->d_out);
     zxc_mi355x_free(b->d_status);
+    zxc_mi355x_free(b->d_dict);
     memset(b, 0, sizeof(*b));
 }
 
 static int run_jobs(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_job_t* jobs, uint32_t n,
                     size_t out_bytes, uint32_t block_size, int verify_trailer, int32_t* h_status,
-                    dev_bufs_t* b) {
+                    dev_bufs_t* b, const dict_ref_t* dr) {
     memset(b, 0, sizeof(*b));
     if (zxc_mi355x_device_count() <= 0) return ZXC_ERROR_GPU_UNAVAILABLE;
     /* +64: the kernel's 16-byte literal / extras reads may run past the last block */
@@ -167,9 +231,23 @@ static int run_jobs(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_job_
     if (b->d_comp && b->d_jobs && b->d_out && b->d_status) {
         rc = zxc_mi355x_memcpy_h2d(b->d_comp, h_comp, comp_bytes);
         if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_h2d(b->d_jobs, jobs, (size_t)n * sizeof(zxc_dev_job_t));
-        if (rc == ZXC_OK)
-            rc = zxc_mi355x_decode_blocks_device(b->d_comp, (const zxc_dev_job_t*)b->d_jobs, n, b->d_out,
-                                                 (int32_t*)b->d_status, block_size, verify_trailer, NULL);
+        if (rc == ZXC_OK && dr && dr->dict_size) {
+            b->d_dict = zxc_mi355x_malloc(dr->dict_size + ZXC_HUF_TABLE_SIZE + 64);
+            if (!b->d_dict) rc = ZXC_ERROR_MEMORY;
+            if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_h2d(b->d_dict, dr->dict, dr->dict_size);
+            if (rc == ZXC_OK && dr->dict_huf)
+                rc = zxc_mi355x_memcpy_h2d((uint8_t*)b->d_dict + dr->dict_size, dr->dict_huf, ZXC_HUF_TABLE_SIZE);
+        }
+        if (rc == ZXC_OK) {
+            if (b->d_dict)
+                rc = zxc_mi355x_decode_blocks_dict_device(b->d_comp, (const zxc_dev_job_t*)b->d_jobs, n, b->d_out,
+                                                          (int32_t*)b->d_status, block_size, verify_trailer, b->d_dict,
+                                                          (uint32_t)dr->dict_size,
+                                                          dr->dict_huf ? (uint8_t*)b->d_dict + dr->dict_size : NULL, NULL);
+            else
+                rc = zxc_mi355x_decode_blocks_device(b->d_comp, (const zxc_dev_job_t*)b->d_jobs, n, b->d_out,
+                                                     (int32_t*)b->d_status, block_size, verify_trailer, NULL);
+        }
         if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(NULL);
         if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(h_status, b->d_status, (size_t)n * sizeof(int32_t));
     }
@@ -195,8 +273,13 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
     const int verify = file_ck && opts && opts->checksum_enabled;
     const uint8_t* dict = opts ? (const uint8_t*)opts->dict : NULL;
     const size_t dict_size = (opts && opts->dict) ? opts->dict_size : 0;
-    if (dict_id != 0 && (!dict || dict_size == 0)) return ZXC_ERROR_DICT_REQUIRED;
-    if (dict_id != 0 || dict_size != 0) return ZXC_ERROR_GPU_UNSUPPORTED; /* dictionary prefix: next scope row */
+    const uint8_t* dict_huf = (opts && opts->dict) ? (const uint8_t*)opts->dict_huf : NULL;
+    if (dict_id != 0) { /* zxc_dispatch.c:883-892 */
+        if (!dict || dict_size == 0) return ZXC_ERROR_DICT_REQUIRED;
+        if (dict_id_of(dict, dict_size, dict_huf) != dict_id) return ZXC_ERROR_DICT_MISMATCH;
+    }
+    if (dict_size > ZXC_DICT_SIZE_MAX) return ZXC_ERROR_DICT_TOO_LARGE;
+    const dict_ref_t dr = {dict, dict_size, dict_huf};
 
     /* Pass 1 (host): walk the 8-byte block headers into a job table. A problem found
      * at block k is only reported if blocks 0..k-1 all decode (the reference stops at
@@ -240,7 +323,7 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
         int32_t* st = (int32_t*)malloc((size_t)n * sizeof(int32_t));
         if (!st) { free(jobs); return ZXC_ERROR_MEMORY; }
         dev_bufs_t b;
-        int rc = run_jobs(src, src_size, jobs, n, (size_t)n * block_size, block_size, verify, st, &b);
+        int rc = run_jobs(src, src_size, jobs, n, (size_t)n * block_size, block_size, verify, st, &b, &dr);
         if (rc != ZXC_OK) { free(st); free(jobs); return rc; }
         /* sequential semantics: first failing block wins; sizes accumulate in order */
         int regular = 1;
@@ -259,7 +342,7 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
             dev_bufs_free(&b);
             const uint32_t slot = (block_size + TAIL_PAD + 15u) & ~15u;
             for (uint32_t i = 0; i < n; i++) { jobs[i].out_off = (uint64_t)i * slot; jobs[i].out_len = slot; }
-            rc = run_jobs(src, src_size, jobs, n, (size_t)n * slot, block_size, verify, st, &b);
+            rc = run_jobs(src, src_size, jobs, n, (size_t)n * slot, block_size, verify, st, &b, &dr);
             if (rc != ZXC_OK) { free(st); free(jobs); return rc; }
             size_t op = 0;
             for (uint32_t i = 0; i < n && rc == ZXC_OK; i++) {
@@ -403,6 +486,10 @@ struct zxc_seekable_s {
     uint32_t dict_id;
     uint32_t* comp_sizes;
     uint64_t* comp_offsets; /* [num_blocks + 1] */
+    uint8_t* dict;          /* owned copy (zxc_seekable_set_dict) */
+    size_t dict_size;
+    uint8_t dict_huf[ZXC_HUF_TABLE_SIZE];
+    int has_dict_huf;
 };
 
 size_t zxc_seek_table_size(const uint32_t num_blocks) { return BLK_HDR + (size_t)num_blocks * 4; }
@@ -426,7 +513,28 @@ void zxc_seekable_free(zxc_seekable* s) {
     if (!s) return;
     free(s->comp_sizes);
     free(s->comp_offsets);
+    free(s->dict);
     free(s);
+}
+
+/* src/lib/zxc_seekable.c:1144-1174 */
+int zxc_seekable_set_dict(zxc_seekable* s, const void* dict, size_t dict_size, const void* dict_huf) {
+    if (!s || !dict || dict_size == 0) return ZXC_ERROR_NULL_INPUT;
+    if (dict_size > ZXC_DICT_SIZE_MAX) return ZXC_ERROR_DICT_TOO_LARGE;
+    if (s->dict_id != 0 && dict_id_of((const uint8_t*)dict, dict_size, (const uint8_t*)dict_huf) != s->dict_id)
+        return ZXC_ERROR_DICT_MISMATCH;
+    free(s->dict);
+    s->dict = (uint8_t*)malloc(dict_size);
+    s->dict_size = 0;
+    s->has_dict_huf = 0;
+    if (!s->dict) return ZXC_ERROR_MEMORY;
+    memcpy(s->dict, dict, dict_size);
+    s->dict_size = dict_size;
+    if (dict_huf) {
+        memcpy(s->dict_huf, dict_huf, ZXC_HUF_TABLE_SIZE);
+        s->has_dict_huf = 1;
+    }
+    return ZXC_OK;
 }
 
 /* shared by both openers: entries = the SEK payload (num_blocks LE u32) */
@@ -548,7 +656,8 @@ int64_t zxc_seekable_decompress_range(zxc_seekable* s, void* dst, const size_t d
     if (!s || !dst) return ZXC_ERROR_NULL_INPUT;
     if (dst_capacity < len) return ZXC_ERROR_DST_TOO_SMALL;
     if (offset + len > s->total_decomp) return ZXC_ERROR_SRC_TOO_SMALL;
-    if (s->dict_id != 0) return ZXC_ERROR_DICT_REQUIRED; /* no zxc_seekable_set_dict in this build */
+    if (s->dict_id != 0 && (!s->dict || s->dict_size == 0)) return ZXC_ERROR_DICT_REQUIRED;
+    const dict_ref_t dr = {s->dict, s->dict_size, s->has_dict_huf ? s->dict_huf : NULL};
 
     const uint32_t b0 = (uint32_t)(offset / s->block_size);
     const uint32_t b1 = (uint32_t)((offset + len - 1) / s->block_size);
@@ -578,7 +687,7 @@ int64_t zxc_seekable_decompress_range(zxc_seekable* s, void* dst, const size_t d
          * the range needs (zxc_seekable.c:758-780): keep whole slots here. */
         for (uint32_t k = 0; k < n; k++) jobs[k].out_len = s->block_size;
         dev_bufs_t b;
-        int rc = run_jobs(h_comp, comp_bytes, jobs, n, (size_t)n * s->block_size, s->block_size, 0, st, &b);
+        int rc = run_jobs(h_comp, comp_bytes, jobs, n, (size_t)n * s->block_size, s->block_size, 0, st, &b, &dr);
         if (rc != ZXC_OK) {
             ret = rc;
         } else {
