@@ -74,6 +74,13 @@ __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { uint32_t v; __built
 __device__ __forceinline__ uint64_t ld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ __forceinline__ v4u ld128(const uint8_t* p) { v4u v; __builtin_memcpy(&v, p, 16); return v; }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// Arguments of an out-of-line device function arrive in VGPRs and count as divergent; this tells
+// the compiler a pointer is wave-uniform again (scalar address arithmetic and branches).
+template <typename T>
+__device__ __forceinline__ T* uni_ptr(T* p) {
+    const uint64_t a = (uint64_t)p;
+    return (T*)(((uint64_t)uni((uint32_t)(a >> 32)) << 32) | uni((uint32_t)a));
+}
 
 // wave-wide inclusive prefix sum (64 lanes) on the DPP crossbar: row_shr 1,2,4,8 scan each
 // 16-lane row, row_bcast:15 / row_bcast:31 carry the row totals across (gfx9 DPP controls).
@@ -202,8 +209,9 @@ __device__ __forceinline__ uint32_t far_rd8(const Out& O, uint32_t q) {
 // One source byte at output position s, where a negative s (as int32) addresses the dictionary
 // prefix that logically precedes the block (reference: d_floor = dst - dict_size,
 // src/lib/zxc_decompress.c:1028).
+template <bool DICT>
 __device__ __forceinline__ uint32_t src_rd8(WaveLds& L, const Out& O, uint32_t s, uint32_t ring_lo) {
-    if ((int32_t)s < 0) return ld8(O.dict + (int32_t)(O.dict_size + s));
+    if (DICT && (int32_t)s < 0) return ld8(O.dict + (int32_t)(O.dict_size + s));
     return s >= ring_lo ? ring_rd8(L, s) : far_rd8(O, s);
 }
 
@@ -226,13 +234,14 @@ __device__ __forceinline__ void flush_to(WaveLds& L, Out& O, uint32_t upto, int 
 // Whole-wave copy of n bytes to output position dpos. The source is either output
 // position spos (ring when >= ring_lo, L2 otherwise; must not overlap the
 // destination: n <= dpos - spos) or, when lit != nullptr, the literal stream.
+template <bool DICT>
 __device__ void coop_copy(WaveLds& L, const Out& O, uint32_t dpos, uint32_t spos, const uint8_t* lit, uint32_t n,
                           uint32_t ring_lo, int lane) {
     const uint32_t h0 = (16u - (dpos & 15u)) & 15u;
     const uint32_t h = h0 < n ? h0 : n;  // bytes up to the first 16-byte boundary
     if ((uint32_t)lane < h) {
         const uint32_t s = spos + lane;
-        const uint32_t b = lit ? ld8(lit + lane) : src_rd8(L, O, s, ring_lo);
+        const uint32_t b = lit ? ld8(lit + lane) : src_rd8<DICT>(L, O, s, ring_lo);
         ring_wr8(L, dpos + lane, b);
     }
     const uint32_t nb = (n - h) >> 4;
@@ -241,9 +250,9 @@ __device__ void coop_copy(WaveLds& L, const Out& O, uint32_t dpos, uint32_t spos
         const uint32_t s = spos + o;
         v4u v;
         if (lit) v = ld128(lit + o);
-        else if ((int32_t)s < 0) {  // (partly) inside the dictionary: byte gather (rare)
+        else if (DICT && (int32_t)s < 0) {  // (partly) inside the dictionary: byte gather (rare)
             uint32_t w[4] = {0, 0, 0, 0};
-            for (uint32_t k = 0; k < 16u; k++) w[k >> 2] |= src_rd8(L, O, s + k, ring_lo) << (8u * (k & 3u));
+            for (uint32_t k = 0; k < 16u; k++) w[k >> 2] |= src_rd8<DICT>(L, O, s + k, ring_lo) << (8u * (k & 3u));
             v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
         } else if (s >= ring_lo) v = ring_rd128(L, s);
         else v = far_rd128(O, s);
@@ -253,7 +262,7 @@ __device__ void coop_copy(WaveLds& L, const Out& O, uint32_t dpos, uint32_t spos
     if ((uint32_t)lane < tl) {
         const uint32_t o = n - tl + lane;
         const uint32_t s = spos + o;
-        const uint32_t b = lit ? ld8(lit + o) : src_rd8(L, O, s, ring_lo);
+        const uint32_t b = lit ? ld8(lit + o) : src_rd8<DICT>(L, O, s, ring_lo);
         ring_wr8(L, dpos + o, b);
     }
     wave_lds_fence();
@@ -263,6 +272,7 @@ __device__ void coop_copy(WaveLds& L, const Out& O, uint32_t dpos, uint32_t spos
 // period-off pattern: copy `dist` bytes from distance `dist`, then the valid periodic
 // region has doubled, so double dist (it stays a multiple of off). With flush_each the
 // ring is drained between steps (giant sequences, longer than the ring).
+template <bool DICT>
 __device__ void coop_match(WaveLds& L, Out& O, uint32_t M, uint32_t ml, uint32_t off, uint32_t ring_lo_fixed,
                            bool flush_each, int lane) {
     uint32_t done = 0, dist = off;
@@ -273,7 +283,7 @@ __device__ void coop_match(WaveLds& L, Out& O, uint32_t M, uint32_t ml, uint32_t
         const uint32_t d = M + done;
         uint32_t ring_lo = ring_lo_fixed;
         if (flush_each) ring_lo = (d + n > RING_BYTES) ? d + n - RING_BYTES : 0u;
-        coop_copy(L, O, d, d - dist, nullptr, n, ring_lo, lane);
+        coop_copy<DICT>(L, O, d, d - dist, nullptr, n, ring_lo, lane);
         done += n;
         if (flush_each) flush_to(L, O, d + n, lane);
         if (n == dist && dist < TILE_MAX) dist <<= 1;
@@ -296,7 +306,7 @@ __device__ __forceinline__ uint32_t compose_map(uint32_t hi, uint32_t lo) {  // 
     return r;
 }
 
-__device__ uint32_t parse_varints(const uint8_t* ext, uint32_t ext_size, uint32_t cur, uint32_t nv, WaveLds& L,
+__device__ __forceinline__ uint32_t parse_varints(const uint8_t* ext, uint32_t ext_size, uint32_t cur, uint32_t nv, WaveLds& L,
                                   int lane) {
     const uint32_t base = cur + 8u * (uint32_t)lane;
     uint64_t lo8;
@@ -403,6 +413,7 @@ __device__ __forceinline__ uint32_t lanes_le(uint32_t sorted, uint32_t x) {
 }
 
 // Executes all sequences of one block. Returns decoded size or a negative error.
+template <bool DICT>
 __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __restrict__ dst, uint32_t out_len, uint32_t cap,
                              WaveLds& L, int lane) {
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -476,7 +487,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
         int err = 0;
         if (real) {
             if (est > cap || len > cap - est || lst > S.n_lit || ll > S.n_lit - lst) err = E_OVERFLOW;
-            else if (off > est + ll + S.dict_size) err = E_BAD_OFFSET;
+            else if (off > est + ll + (DICT ? S.dict_size : 0u)) err = E_BAD_OFFSET;
         } else if (valid) {  // pseudo sequence: whatever literals are left
             if (est > cap || lst > S.n_lit || S.n_lit - lst > cap - est) err = E_OVERFLOW;
             else { ll = S.n_lit - lst; len = ll; }
@@ -500,13 +511,13 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             uint32_t donel = 0;
             while (donel < gll) {
                 const uint32_t n = (gll - donel < TILE_MAX) ? gll - donel : TILE_MAX;
-                coop_copy(L, O, p + donel, 0, S.lit + lp + donel, n, 0, lane);
+                coop_copy<DICT>(L, O, p + donel, 0, S.lit + lp + donel, n, 0, lane);
                 donel += n;
                 flush_to(L, O, p + donel, lane);
             }
             if (gml) {
                 __builtin_amdgcn_s_waitcnt(0);  // earlier flush stores must have left before reading them back
-                coop_match(L, O, p + gll, gml, goff, 0, true, lane);
+                coop_match<DICT>(L, O, p + gll, gml, goff, 0, true, lane);
             }
             p += gll + gml;
             lp += gll;
@@ -538,7 +549,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                     const int j = __ffsll((unsigned long long)lm) - 1;
                     lm &= lm - 1ull;
                     const uint32_t jl = __shfl(ll, j), je = __shfl(est, j), js = __shfl(lst, j);
-                    coop_copy(L, O, je, 0, S.lit + js, jl, 0, lane);
+                    coop_copy<DICT>(L, O, je, 0, S.lit + js, jl, 0, lane);
                 }
                 wave_lds_fence();
             }
@@ -546,7 +557,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             // ---- matches. Sequence i may only copy once every earlier match of this batch
             // that overlaps its source [qa, qb) is finished: those are lanes ja..jb.
             const uint32_t Es = mine ? E : 0xFFFFFFFFu, Ms = mine ? M : 0xFFFFFFFFu;
-            const bool fromdict = off > M;  // source starts inside the dictionary prefix
+            const bool fromdict = DICT && off > M;  // source starts inside the dictionary prefix
             const uint32_t qa = M - off;    // (wraps negative then; only src_rd8 / coop paths read it)
             const uint32_t qb = fromdict ? ((off - M < ml) ? ((ml - (off - M) < M) ? ml - (off - M) : M) : 0u)
                                          : ((qa + ml < M) ? qa + ml : M);
@@ -649,7 +660,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                     const uint32_t jM = __shfl(M, j), jml = __shfl(ml, j), joff = __shfl(off, j);
                     if (S.dbg & DBG_NO_LONG) continue;
                     if (jM - joff < ring_lo && !far_waited) { __builtin_amdgcn_s_waitcnt(0); far_waited = true; }
-                    coop_match(L, O, jM, jml, joff, ring_lo, false, lane);
+                    coop_match<DICT>(L, O, jM, jml, joff, ring_lo, false, lane);
                 }
                 if (can) pending = false;
                 wave_lds_fence();
@@ -712,72 +723,99 @@ __device__ __forceinline__ void scratch_release(ScratchPool& sp, int lane) {
 }
 
 // RLE literal section -> scratch (reference src/lib/zxc_decompress.c:906-975).
-// Tokens form a chain (a raw token skips its payload), so every lane decodes the byte
-// at window position `lane` as if it were a token, and the scalar unit walks the chain
-// through the per-lane jump distances with v_readlane (no memory latency per token).
-// The lanes that turned out to be tokens then expand in lockstep with exact-length
-// 16/8/4/2/1-byte global stores.
+// Tokens form a chain (a raw token skips its payload), so finding them is sequential, but it is
+// only "read a byte, add": the scalar unit walks the chain over a 256-byte window held one dword
+// per lane (v_readlane), four windows prefetched ahead, and hands token k of a batch to lane k
+// (v_writelane). The 64 tokens of a batch then expand in lockstep, every lane copying / filling
+// its own 1..131 bytes with exact-length 16/8/4/2/1-byte global stores. Walking costs ~15 scalar
+// instructions per token; the memory latency of the payload copies is paid once per 64 tokens.
 __device__ __forceinline__ void st_bytes(uint8_t* d, const void* v, int nbytes) { __builtin_memcpy(d, v, nbytes); }
 
-__device__ int rle_expand(const uint8_t* __restrict__ r, uint32_t rsize, uint8_t* __restrict__ w, uint32_t n, int lane) {
-    uint32_t base = 0, wpos = 0;
+// v[lane_idx] = val, both wave-uniform (v_writelane_b32)
+__device__ __forceinline__ void put_lane(uint32_t& v, uint32_t val, uint32_t lane_idx) {
+    // (gfx9 VOP3 reads one SGPR through the constant bus; the lane select goes through m0)
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val), "s"(lane_idx) : "m0");
+}
+
+__device__ __forceinline__ uint32_t rle_window(const uint8_t* __restrict__ r, uint32_t rsize, uint32_t base, int lane) {
+    const uint32_t a = base + 4u * (uint32_t)lane;
+    if (a + 4u <= rsize) return ld32(r + a);
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < 4u; k++)
+        if (a + k < rsize) v |= ld8(r + a + k) << (8u * k);
+    return v;
+}
+
+__device__ int rle_expand(const uint8_t* __restrict__ r_, uint32_t rsize, uint8_t* __restrict__ w_, uint32_t n, int lane) {
+    const uint8_t* __restrict__ r = uni_ptr(r_);
+    uint8_t* __restrict__ w = uni_ptr(w_);
+    rsize = uni(rsize);
+    n = uni(n);
+    uint32_t pos = 0, dst = 0;  // wave-uniform: chain position in r, bytes produced
+    uint32_t wbase = 0;
+    uint32_t q0 = rle_window(r, rsize, 0u, lane), q1 = rle_window(r, rsize, 256u, lane),
+             q2 = rle_window(r, rsize, 512u, lane), q3 = rle_window(r, rsize, 768u, lane);
     int rc = 0;
-    while (base < rsize && wpos < n) {
-        const uint32_t pos_l = base + (uint32_t)lane;
-        const uint32_t tok = pos_l < rsize ? ld8(r + pos_l) : 0u;
-        const bool israw = !(tok & 0x80u);
-        const uint32_t len = israw ? tok + 1u : (tok & 0x7Fu) + 4u;
-        const uint32_t nxt = (uint32_t)lane + (israw ? len + 1u : 2u);
-        const uint32_t limit = (rsize - base < 64u) ? rsize - base : 64u;
-        uint64_t mask = 0;
-        uint32_t pos = 0;
-        while (pos < limit) {  // scalar chain walk
-            mask |= 1ull << pos;
-            pos = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)pos);
+    while (pos < rsize && dst < n) {
+        // ---- phase A: the next (up to) 64 tokens, token k -> lane k
+        uint32_t tpos = 0, tdst = 0, tbyte = 0, ntok = 0;
+        while (ntok < 64u && pos < rsize && dst < n) {
+            while (pos - wbase >= 256u) {
+                q0 = q1; q1 = q2; q2 = q3;
+                wbase += 256u;
+                q3 = rle_window(r, rsize, wbase + 768u, lane);
+            }
+            const uint32_t rel = pos - wbase;
+            const uint32_t dw = (uint32_t)__builtin_amdgcn_readlane((int)q0, (int)(rel >> 2));
+            const uint32_t tb = (dw >> (8u * (rel & 3u))) & 255u;
+            const bool raw = !(tb & 0x80u);
+            put_lane(tpos, pos, ntok);
+            put_lane(tdst, dst, ntok);
+            put_lane(tbyte, tb, ntok);
+            dst += raw ? tb + 1u : (tb & 0x7Fu) + 4u;
+            pos += raw ? tb + 2u : 2u;
+            ntok++;
         }
-        const bool istok = (mask >> lane) & 1ull;
-        const uint32_t olen = istok ? len : 0u;
-        const uint32_t incl = wave_scan_add(olen, lane);
-        const uint32_t doff = wpos + incl - olen;
-        const bool live = istok && doff < n;  // the reference stops taking tokens once n bytes are out
-        const uint32_t ri = pos_l + 1u;
-        const bool bad = live && ((n - doff < len) || (israw ? (ri > rsize || rsize - ri < len) : (ri >= rsize)));
+        // ---- phase B: lane k expands token k
+        const bool live = (uint32_t)lane < ntok;  // (the reference stops taking tokens once n bytes are out)
+        const bool israw = !(tbyte & 0x80u);
+        const uint32_t len = israw ? tbyte + 1u : (tbyte & 0x7Fu) + 4u;
+        const uint32_t ri = tpos + 1u;
+        const bool bad = live && ((n - tdst < len) || (israw ? (ri > rsize || rsize - ri < len) : (ri >= rsize)));
         if (__ballot(bad)) { rc = E_CORRUPT; break; }
         const uint8_t* sp = r + ri;
-        uint8_t* dp = w + doff;
-        v4u fill;
+        uint8_t* dp = w + tdst;
+        v4u fill = {0, 0, 0, 0};
         if (!israw) {
-            const uint32_t b = live ? ld8(sp) : 0u;
-            const uint32_t b4 = b * 0x01010101u;
+            const uint32_t b4 = (live ? ld8(sp) : 0u) * 0x01010101u;
             fill.x = b4; fill.y = b4; fill.z = b4; fill.w = b4;
         }
 #pragma unroll 1
-        for (uint32_t o = 0; o < 144u; o += 16u) {
-            const bool act = live && o + 16u <= len;
-            if (__ballot(act) == 0ull) break;
-            if (act) {
-                const v4u v = israw ? ld128(sp + o) : fill;
-                st_bytes(dp + o, &v, 16);
-            }
+        for (uint32_t o = 0; o < 128u; o += 32u) {  // two 16-byte pieces in flight per step
+            const bool a0 = live && o + 16u <= len, a1 = live && o + 32u <= len;
+            if (__ballot(a0) == 0ull) break;
+            v4u v0 = fill, v1 = fill;
+            if (a0 && israw) v0 = ld128(sp + o);
+            if (a1 && israw) v1 = ld128(sp + o + 16u);
+            if (a0) st_bytes(dp + o, &v0, 16);
+            if (a1) st_bytes(dp + o + 16u, &v1, 16);
         }
-        if (live) {  // exact tail: 8 / 4 / 2 / 1
+        if (live) {  // exact tail: 8 / 4 / 2 / 1 (and the 16-byte piece at 128 of a 131-byte run)
             uint32_t o = len & ~15u;
             if (len & 8u) { uint64_t v = israw ? ld64(sp + o) : ((uint64_t)fill.x << 32 | fill.x); st_bytes(dp + o, &v, 8); o += 8u; }
             if (len & 4u) { uint32_t v = israw ? ld32(sp + o) : fill.x; st_bytes(dp + o, &v, 4); o += 4u; }
             if (len & 2u) { uint16_t v = (uint16_t)(israw ? ld16(sp + o) : fill.x); st_bytes(dp + o, &v, 2); o += 2u; }
             if (len & 1u) { dp[o] = (uint8_t)(israw ? ld8(sp + o) : fill.x); }
         }
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        wpos = (__ballot(istok && !live) != 0ull) ? n : wpos + total;
-        base += pos;
     }
-    if (rc == 0 && wpos != n) rc = E_CORRUPT;
+    if (rc == 0 && dst != n) rc = E_CORRUPT;
     // every lane is about to read the scratch with ordinary (L1-cached) loads
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return rc;
 }
 
+template <bool DICT>
 __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t comp_sz, bool ghi, uint8_t* dst, uint32_t out_len,
                                uint32_t cap, uint32_t block_size, ScratchPool& pool, WaveLds& L, int lane,
                                uint32_t dbg, const uint8_t* dict, uint32_t dict_size, const uint8_t* dict_huf) {
@@ -801,7 +839,7 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
         S.off8 = 0;
         S.ext = S.tok + 4ull * S.n_seq;
         S.ext_size = avail - (uint32_t)consumed;
-        return run_sequences(S, dst, out_len, cap, L, lane);
+        return run_sequences<DICT>(S, dst, out_len, cap, L, lane);
     }
     const uint32_t desc = (enc_lit != 0u ? 4u : 0u) + (enc_tok == 2u ? 4u : 0u);
     if (comp_sz < 12u + desc) return E_BAD_HEADER;
@@ -860,25 +898,33 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
     S.off8 = enc_off;
     S.ext = S.offs + sz_off;
     S.ext_size = avail - (uint32_t)consumed;
-    return run_sequences(S, dst, out_len, cap, L, lane);
+    return run_sequences<DICT>(S, dst, out_len, cap, L, lane);
 }
 
 #ifndef WAVES_PER_SIMD
 #define WAVES_PER_SIMD 1
 #endif
-extern "C" __global__ void __launch_bounds__(64, WAVES_PER_SIMD)
-zxc_decode_blocks_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
-                         uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,
-                         uint32_t trailer_bytes, uint8_t* __restrict__ scratch, uint32_t scratch_stride, uint32_t dbg,
-                         uint32_t* __restrict__ slot_busy, uint32_t n_slots, const uint8_t* __restrict__ dict,
-                         uint32_t dict_size, const uint8_t* __restrict__ dict_huf) {
+template <bool DICT>
+__device__ __forceinline__ void decode_one_block(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs,
+                                                 uint32_t n_jobs, uint8_t* __restrict__ out, int32_t* __restrict__ status,
+                                                 uint32_t block_size, uint32_t trailer_bytes, uint8_t* __restrict__ scratch,
+                                                 uint32_t scratch_stride, uint32_t dbg, uint32_t* __restrict__ slot_busy,
+                                                 uint32_t n_slots, const uint8_t* __restrict__ dict, uint32_t dict_size,
+                                                 const uint8_t* __restrict__ dict_huf) {
     // One workgroup (= one wavefront) per block: the hardware dispatcher hands out blocks as
     // wave slots free up, which is all the dynamic scheduling RAW-vs-dense blocks need.
+#ifdef EXP_NO_PIV_LDS  // experiment only: occupancy without the PivCo tables (levels 6-7 break)
+    __shared__ union { WaveLds w; } lds;
+#else
     __shared__ union { WaveLds w; PivLds p; } lds;  // the PivCo tables reuse the ring's LDS (never live together)
+#endif
     WaveLds& L = lds.w;
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (b >= n_jobs) return;
+#ifdef EXP_TIMES  // experiment only: status = start (hi 16) and duration (lo 16) in units of 32 ticks of the 100 MHz clock
+    const uint64_t t_start = wall_clock64();
+#endif
     const uint32_t cap = block_size + 2112u;  // the reference always decodes with block_size + ZXC_DECOMPRESS_TAIL_PAD
     ScratchPool pool = {scratch, scratch_stride, slot_busy, n_slots, -1};
     const uint64_t comp_off = jobs[b].comp_off;
@@ -897,7 +943,7 @@ zxc_decode_blocks_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* 
         } else if (trailer_bytes && wave_checksum32(src + 8, comp_sz, lane) != uni(ld32(src + 8 + comp_sz))) {
             rc = E_BAD_CHECKSUM;  // per-block checksum of the compressed payload (zxc_decompress.c:1662-1666)
         } else if (type == 1u || type == 2u) {
-            rc = decode_lz_block(src + 8, comp_sz, type == 2u, dst, out_len, cap, block_size, pool, L, lane, dbg, dict,
+            rc = decode_lz_block<DICT>(src + 8, comp_sz, type == 2u, dst, out_len, cap, block_size, pool, L, lane, dbg, dict,
                                  dict_size, dict_huf);
             scratch_release(pool, lane);
         } else if (type == 0u) {  // RAW: stored bytes
@@ -925,5 +971,31 @@ zxc_decode_blocks_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* 
             rc = E_BAD_BLOCK_TYPE;
         }
     }
+#ifdef EXP_TIMES
+    __builtin_amdgcn_s_waitcnt(0);
+    const uint64_t t_end = wall_clock64();
+    rc = (int)((((uint32_t)(t_start >> 5) & 0xFFFFu) << 16) | (uint32_t)(((t_end - t_start) >> 5) & 0xFFFFu));
+#endif
     if (lane == 0) status[b] = rc;
+}
+
+// Two entry points: archives without a dictionary (the common case and the benchmarked path) run
+// the variant with every dictionary branch compiled out.
+extern "C" __global__ void __launch_bounds__(64, WAVES_PER_SIMD)
+zxc_decode_blocks_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
+                         uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,
+                         uint32_t trailer_bytes, uint8_t* __restrict__ scratch, uint32_t scratch_stride, uint32_t dbg,
+                         uint32_t* __restrict__ slot_busy, uint32_t n_slots) {
+    decode_one_block<false>(comp, jobs, n_jobs, out, status, block_size, trailer_bytes, scratch, scratch_stride, dbg,
+                            slot_busy, n_slots, nullptr, 0u, nullptr);
+}
+
+extern "C" __global__ void __launch_bounds__(64, WAVES_PER_SIMD)
+zxc_decode_blocks_dict_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
+                              uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,
+                              uint32_t trailer_bytes, uint8_t* __restrict__ scratch, uint32_t scratch_stride, uint32_t dbg,
+                              uint32_t* __restrict__ slot_busy, uint32_t n_slots, const uint8_t* __restrict__ dict,
+                              uint32_t dict_size, const uint8_t* __restrict__ dict_huf) {
+    decode_one_block<true>(comp, jobs, n_jobs, out, status, block_size, trailer_bytes, scratch, scratch_stride, dbg,
+                           slot_busy, n_slots, dict, dict_size, dict_huf);
 }

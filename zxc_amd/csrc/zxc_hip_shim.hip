@@ -11,8 +11,12 @@
 extern "C" __global__ void zxc_decode_blocks_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                     uint8_t* out, int32_t* status, uint32_t block_size,
                                                     uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride, uint32_t dbg,
-                                                    uint32_t* slot_busy, uint32_t n_slots, const uint8_t* dict,
-                                                    uint32_t dict_size, const uint8_t* dict_huf);
+                                                    uint32_t* slot_busy, uint32_t n_slots);
+extern "C" __global__ void zxc_decode_blocks_dict_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
+                                                         uint8_t* out, int32_t* status, uint32_t block_size,
+                                                         uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride,
+                                                         uint32_t dbg, uint32_t* slot_busy, uint32_t n_slots,
+                                                         const uint8_t* dict, uint32_t dict_size, const uint8_t* dict_huf);
 
 extern "C" __global__ void zxc_encode_blocks_kernel(const uint8_t* src, uint64_t src_size, uint32_t block_size, uint8_t* slots,
                                                     uint32_t slot_stride, uint32_t* sizes, uint32_t n_blocks, uint32_t with_checksum);
@@ -118,10 +122,15 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
         if (hipMalloc((void**)&g_dev[dev].counter, (size_t)8192 * 4u) != hipSuccess) return ZXC_ERROR_MEMORY;
         if (hipMemset(g_dev[dev].counter, 0, (size_t)8192 * 4u) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
     }
-    hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
-                       d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, verify_trailer ? 4u : 0u,
-                       g_dev[dev].scratch, stride, g_debug_flags, g_dev[dev].counter, n_slots, (const uint8_t*)d_dict,
-                       dict_size, (const uint8_t*)d_dict_huf);
+    if (d_dict || d_dict_huf)
+        hipLaunchKernelGGL(zxc_decode_blocks_dict_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream,
+                           (const uint8_t*)d_comp, d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size,
+                           verify_trailer ? 4u : 0u, g_dev[dev].scratch, stride, g_debug_flags, g_dev[dev].counter, n_slots,
+                           (const uint8_t*)d_dict, dict_size, (const uint8_t*)d_dict_huf);
+    else
+        hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
+                           d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, verify_trailer ? 4u : 0u,
+                           g_dev[dev].scratch, stride, g_debug_flags, g_dev[dev].counter, n_slots);
     return hipGetLastError() == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
 }
 
