@@ -25,7 +25,8 @@ def step(): zxc_amd.decode_blocks_device(d_comp.data_ptr(), d_jobs.data_ptr(), j
 step(); step(); torch.cuda.synchronize()
 st = d_st.cpu().numpy().view(np.uint32)
 start = (st >> 16).astype(np.int64); dur = (st & 0xFFFF).astype(np.float64) * 0.32  # us
-start = (((start - start[0] + 0x1000) & 0xFFFF) - 0x1000).astype(np.float64) * 0.32
+piv = int(np.median(start))
+start = (((start - piv + 0x8000) & 0xFFFF) - 0x8000).astype(np.float64) * 0.32
 start -= start.min()
 end = start + dur
 print(f"blocks {st.size}  kernel span {end.max():.0f} us  mean block {dur.mean():.0f} us  p50 {np.percentile(dur,50):.0f}  p90 {np.percentile(dur,90):.0f}  p99 {np.percentile(dur,99):.0f}  max {dur.max():.0f}")

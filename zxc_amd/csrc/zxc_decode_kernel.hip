@@ -725,17 +725,10 @@ __device__ __forceinline__ void scratch_release(ScratchPool& sp, int lane) {
 // RLE literal section -> scratch (reference src/lib/zxc_decompress.c:906-975).
 // Tokens form a chain (a raw token skips its payload), so finding them is sequential, but it is
 // only "read a byte, add": the scalar unit walks the chain over a 256-byte window held one dword
-// per lane (v_readlane), four windows prefetched ahead, and hands token k of a batch to lane k
-// (v_writelane). The 64 tokens of a batch then expand in lockstep, every lane copying / filling
+// per lane (v_readlane), four windows prefetched ahead, and hands token k of a batch to lane k. The 64 tokens of a batch then expand in lockstep, every lane copying / filling
 // its own 1..131 bytes with exact-length 16/8/4/2/1-byte global stores. Walking costs ~15 scalar
 // instructions per token; the memory latency of the payload copies is paid once per 64 tokens.
 __device__ __forceinline__ void st_bytes(uint8_t* d, const void* v, int nbytes) { __builtin_memcpy(d, v, nbytes); }
-
-// v[lane_idx] = val, both wave-uniform (v_writelane_b32)
-__device__ __forceinline__ void put_lane(uint32_t& v, uint32_t val, uint32_t lane_idx) {
-    // (gfx9 VOP3 reads one SGPR through the constant bus; the lane select goes through m0)
-    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val), "s"(lane_idx) : "m0");
-}
 
 __device__ __forceinline__ uint32_t rle_window(const uint8_t* __restrict__ r, uint32_t rsize, uint32_t base, int lane) {
     const uint32_t a = base + 4u * (uint32_t)lane;
@@ -769,9 +762,10 @@ __device__ int rle_expand(const uint8_t* __restrict__ r_, uint32_t rsize, uint8_
             const uint32_t dw = (uint32_t)__builtin_amdgcn_readlane((int)q0, (int)(rel >> 2));
             const uint32_t tb = (dw >> (8u * (rel & 3u))) & 255u;
             const bool raw = !(tb & 0x80u);
-            put_lane(tpos, pos, ntok);
-            put_lane(tdst, dst, ntok);
-            put_lane(tbyte, tb, ntok);
+            const bool me = (uint32_t)lane == ntok;  // one v_cmp + three v_cndmask with scalar sources
+            tpos = me ? pos : tpos;
+            tdst = me ? dst : tdst;
+            tbyte = me ? tb : tbyte;
             dst += raw ? tb + 1u : (tb & 0x7Fu) + 4u;
             pos += raw ? tb + 2u : 2u;
             ntok++;
@@ -909,7 +903,8 @@ __device__ __forceinline__ void decode_one_block(const uint8_t* __restrict__ com
                                                  uint32_t n_jobs, uint8_t* __restrict__ out, int32_t* __restrict__ status,
                                                  uint32_t block_size, uint32_t trailer_bytes, uint8_t* __restrict__ scratch,
                                                  uint32_t scratch_stride, uint32_t dbg, uint32_t* __restrict__ slot_busy,
-                                                 uint32_t n_slots, const uint8_t* __restrict__ dict, uint32_t dict_size,
+                                                 uint32_t n_slots, const uint32_t* __restrict__ order,
+                                                 const uint8_t* __restrict__ dict, uint32_t dict_size,
                                                  const uint8_t* __restrict__ dict_huf) {
     // One workgroup (= one wavefront) per block: the hardware dispatcher hands out blocks as
     // wave slots free up, which is all the dynamic scheduling RAW-vs-dense blocks need.
@@ -920,8 +915,9 @@ __device__ __forceinline__ void decode_one_block(const uint8_t* __restrict__ com
 #endif
     WaveLds& L = lds.w;
     const int lane = threadIdx.x;
-    const uint32_t b = blockIdx.x;
-    if (b >= n_jobs) return;
+    if (blockIdx.x >= n_jobs) return;
+    // heaviest blocks first when the launch is long enough for the tail to matter (see zxc_order_* below)
+    const uint32_t b = order ? uni(order[blockIdx.x]) : blockIdx.x;
 #ifdef EXP_TIMES  // experiment only: status = start (hi 16) and duration (lo 16) in units of 32 ticks of the 100 MHz clock
     const uint64_t t_start = wall_clock64();
 #endif
@@ -985,17 +981,70 @@ extern "C" __global__ void __launch_bounds__(64, WAVES_PER_SIMD)
 zxc_decode_blocks_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
                          uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,
                          uint32_t trailer_bytes, uint8_t* __restrict__ scratch, uint32_t scratch_stride, uint32_t dbg,
-                         uint32_t* __restrict__ slot_busy, uint32_t n_slots) {
+                         uint32_t* __restrict__ slot_busy, uint32_t n_slots, const uint32_t* __restrict__ order) {
     decode_one_block<false>(comp, jobs, n_jobs, out, status, block_size, trailer_bytes, scratch, scratch_stride, dbg,
-                            slot_busy, n_slots, nullptr, 0u, nullptr);
+                            slot_busy, n_slots, order, nullptr, 0u, nullptr);
 }
 
 extern "C" __global__ void __launch_bounds__(64, WAVES_PER_SIMD)
 zxc_decode_blocks_dict_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
                               uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,
                               uint32_t trailer_bytes, uint8_t* __restrict__ scratch, uint32_t scratch_stride, uint32_t dbg,
-                              uint32_t* __restrict__ slot_busy, uint32_t n_slots, const uint8_t* __restrict__ dict,
-                              uint32_t dict_size, const uint8_t* __restrict__ dict_huf) {
+                              uint32_t* __restrict__ slot_busy, uint32_t n_slots, const uint32_t* __restrict__ order,
+                              const uint8_t* __restrict__ dict, uint32_t dict_size, const uint8_t* __restrict__ dict_huf) {
     decode_one_block<true>(comp, jobs, n_jobs, out, status, block_size, trailer_bytes, scratch, scratch_stride, dbg,
-                           slot_busy, n_slots, dict, dict_size, dict_huf);
+                           slot_busy, n_slots, order, dict, dict_size, dict_huf);
+}
+
+// ------------------------------------------------------------------ launch order
+// A launch ends when its slowest block ends, and block cost varies ~3x with the number of
+// sequences and the literal coding. For launches of many rounds the blocks are dispatched
+// heaviest-first (longest-processing-time order): a 64-bucket counting sort on a cost estimate
+// read from each block header. order[0 .. n) = job indices; hist[0..64) counts, hist[64..128) cursors.
+__device__ __forceinline__ uint32_t order_bucket(const uint8_t* __restrict__ comp, const zxc_dev_job_t& j, uint32_t block_size) {
+    uint32_t cost = 0;
+    if (j.comp_size >= 8u + 12u) {
+        const uint8_t* h = comp + j.comp_off;
+        const uint32_t type = ld8(h);
+        if (type == 1u || type == 2u) {
+            const uint32_t n_seq = ld32(h + 8), n_lit = ld32(h + 12), enc_lit = ld8(h + 16), enc_tok = ld8(h + 17);
+            cost = n_seq + (enc_tok == 2u ? n_seq : 0u) + (enc_lit == 1u ? n_lit >> 4 : 0u) + (enc_lit >= 2u ? n_lit >> 2 : 0u);
+        }
+    }
+    const uint64_t q = (uint64_t)cost * 320u / block_size;  // cost tops out near block_size / 5
+    return 63u - (q > 63u ? 63u : (uint32_t)q);              // bucket 0 = heaviest
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+zxc_order_hist_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
+                      uint32_t block_size, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t cnt[64];  // per-workgroup counts first: 64 global atomics per workgroup, not 256
+    if (threadIdx.x < 64u) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n_jobs) atomicAdd(cnt + order_bucket(comp, jobs[i], block_size), 1u);
+    __syncthreads();
+    if (threadIdx.x < 64u && cnt[threadIdx.x]) atomicAdd(hist + threadIdx.x, cnt[threadIdx.x]);
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+zxc_order_scatter_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
+                         uint32_t block_size, uint32_t* __restrict__ hist, uint32_t* __restrict__ order) {
+    __shared__ uint32_t cnt[64], base[64];
+    if (threadIdx.x < 64u) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t bk = 0, rank = 0;
+    if (i < n_jobs) {
+        bk = order_bucket(comp, jobs[i], block_size);
+        rank = atomicAdd(cnt + bk, 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64u) {  // this workgroup's slice of every bucket it touches
+        uint32_t s = 0;
+        for (uint32_t k = 0; k < threadIdx.x; k++) s += hist[k];
+        base[threadIdx.x] = cnt[threadIdx.x] ? s + atomicAdd(hist + 64u + threadIdx.x, cnt[threadIdx.x]) : 0u;
+    }
+    __syncthreads();
+    if (i < n_jobs) order[base[bk] + rank] = i;
 }

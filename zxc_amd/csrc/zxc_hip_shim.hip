@@ -2,6 +2,7 @@
 // extern "C" entry points declared in include/zxc_mi355x.h; host C code
 // (zxc_host.c) and external callers use plain pointers and sizes only.
 #include <hip/hip_runtime.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -11,12 +12,17 @@
 extern "C" __global__ void zxc_decode_blocks_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                     uint8_t* out, int32_t* status, uint32_t block_size,
                                                     uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride, uint32_t dbg,
-                                                    uint32_t* slot_busy, uint32_t n_slots);
+                                                    uint32_t* slot_busy, uint32_t n_slots, const uint32_t* order);
+extern "C" __global__ void zxc_order_hist_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
+                                                 uint32_t block_size, uint32_t* hist);
+extern "C" __global__ void zxc_order_scatter_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
+                                                    uint32_t block_size, uint32_t* hist, uint32_t* order);
 extern "C" __global__ void zxc_decode_blocks_dict_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                          uint8_t* out, int32_t* status, uint32_t block_size,
                                                          uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride,
                                                          uint32_t dbg, uint32_t* slot_busy, uint32_t n_slots,
-                                                         const uint8_t* dict, uint32_t dict_size, const uint8_t* dict_huf);
+                                                         const uint32_t* order, const uint8_t* dict, uint32_t dict_size,
+                                                         const uint8_t* dict_huf);
 
 extern "C" __global__ void zxc_encode_blocks_kernel(const uint8_t* src, uint64_t src_size, uint32_t block_size, uint8_t* slots,
                                                     uint32_t slot_stride, uint32_t* sizes, uint32_t n_blocks, uint32_t with_checksum);
@@ -26,13 +32,18 @@ extern "C" __global__ void zxc_gather_blocks_kernel(const uint8_t* slots, uint32
 // Per-device scratch for expanded literal / token sections: one slot per resident
 // workgroup. Grown on demand, never shrunk; freed at process exit by the driver.
 #define ZXC_MAX_DEVICES 16
+#define ZXC_ORDER_STREAMS 8
 static struct {
     uint8_t* scratch;
     size_t bytes;
     int cus;
     int wg_per_cu;
     uint32_t* counter; /* scratch-slot busy flags */
+    /* launch-order buffers ([128 u32 histogram + cursors | order[n]]), one per stream seen: launches on
+     * one stream are ordered, so a stream's buffer is free again when its next launch is enqueued */
+    struct { void* stream; uint32_t* buf; size_t cap; int used; } ord[ZXC_ORDER_STREAMS];
 } g_dev[ZXC_MAX_DEVICES];
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static uint32_t g_debug_flags = 0;  // timing ablations, set only by zxc_mi355x__set_debug
 
@@ -89,6 +100,8 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
     if (block_size < (1u << 12) || block_size > (1u << 21) || (block_size & (block_size - 1u))) return ZXC_ERROR_BAD_BLOCK_SIZE;
     const int dev = current_device();
     if (dev < 0) return ZXC_ERROR_GPU_UNAVAILABLE;
+    struct Unlock { ~Unlock() { pthread_mutex_unlock(&g_lock); } } unlock_on_return;
+    pthread_mutex_lock(&g_lock);
     if (g_dev[dev].cus == 0) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
@@ -122,15 +135,42 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
         if (hipMalloc((void**)&g_dev[dev].counter, (size_t)8192 * 4u) != hipSuccess) return ZXC_ERROR_MEMORY;
         if (hipMemset(g_dev[dev].counter, 0, (size_t)8192 * 4u) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
     }
+    // Heaviest-first dispatch order once the launch spans more than one round of resident workgroups.
+    uint32_t* order = NULL;
+    if (n_jobs > max_slots && !(g_debug_flags & 0x80000000u)) {
+        int k = -1;
+        for (int i = 0; i < ZXC_ORDER_STREAMS; i++)
+            if (g_dev[dev].ord[i].used && g_dev[dev].ord[i].stream == stream) k = i;
+        for (int i = 0; k < 0 && i < ZXC_ORDER_STREAMS; i++)
+            if (!g_dev[dev].ord[i].used) { k = i; g_dev[dev].ord[i].used = 1; g_dev[dev].ord[i].stream = stream; }
+        if (k >= 0) {  // (more distinct streams than buffers: plain order, still correct)
+            const size_t want = 128u + (size_t)n_jobs;
+            if (g_dev[dev].ord[k].cap < want) {
+                if (g_dev[dev].ord[k].buf) (void)hipFree(g_dev[dev].ord[k].buf);
+                g_dev[dev].ord[k].buf = NULL;
+                g_dev[dev].ord[k].cap = 0;
+                if (hipMalloc((void**)&g_dev[dev].ord[k].buf, want * 4u) == hipSuccess) g_dev[dev].ord[k].cap = want;
+            }
+            uint32_t* buf = g_dev[dev].ord[k].buf;
+            if (buf && hipMemsetAsync(buf, 0, 128u * 4u, (hipStream_t)stream) == hipSuccess) {
+                const uint32_t g = (n_jobs + 255u) / 256u;
+                hipLaunchKernelGGL(zxc_order_hist_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
+                                   d_jobs, n_jobs, block_size, buf);
+                hipLaunchKernelGGL(zxc_order_scatter_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream,
+                                   (const uint8_t*)d_comp, d_jobs, n_jobs, block_size, buf, buf + 128);
+                order = buf + 128;
+            }
+        }
+    }
     if (d_dict || d_dict_huf)
         hipLaunchKernelGGL(zxc_decode_blocks_dict_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream,
                            (const uint8_t*)d_comp, d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size,
                            verify_trailer ? 4u : 0u, g_dev[dev].scratch, stride, g_debug_flags, g_dev[dev].counter, n_slots,
-                           (const uint8_t*)d_dict, dict_size, (const uint8_t*)d_dict_huf);
+                           order, (const uint8_t*)d_dict, dict_size, (const uint8_t*)d_dict_huf);
     else
         hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
                            d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, verify_trailer ? 4u : 0u,
-                           g_dev[dev].scratch, stride, g_debug_flags, g_dev[dev].counter, n_slots);
+                           g_dev[dev].scratch, stride, g_debug_flags, g_dev[dev].counter, n_slots, order);
     return hipGetLastError() == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
 }
 
