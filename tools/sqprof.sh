@@ -9,6 +9,6 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY GRBM_GUI_ACTIVE" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC"; do
   i=$((i+1))
-  rocprofv3 --pmc $set -d $R/gpurun_out/${tag}_sq$i -o s --output-format csv -- $CMD > $R/gpurun_out/${tag}_sq$i.log 2>&1
+  timeout -k 5 60 rocprofv3 --pmc $set -d $R/gpurun_out/${tag}_sq$i -o s --output-format csv -- $CMD > $R/gpurun_out/${tag}_sq$i.log 2>&1
   tail -2 $R/gpurun_out/${tag}_sq$i.log | cut -c1-300
 done

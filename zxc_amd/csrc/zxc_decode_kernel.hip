@@ -36,6 +36,9 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 #define RING_MASK (RING_BYTES - 1u)
 #define RING_WORDS (RING_BYTES / 4u)
 #define RING_WMASK (RING_WORDS - 1u)
+#ifndef SPARSE_MAX
+#define SPARSE_MAX 8   // at most this many unfinished sequences after a round: finish them one by one
+#endif
 #define TILE_MAX (RING_BYTES / 2u)   // a batch never spans more output than this (half the ring)
 #define SHORT_MAX 32u    // one register step of a lane-per-sequence copy
 #define MED_MAX 128u     // matches up to this long are copied lane-per-sequence (4 steps)
@@ -59,6 +62,13 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 #define DBG_NO_LONG 16u
 #define DBG_NO_DEPS 32u
 #define DBG_NO_SHORT 64u
+#define DBG_LIT_L1 128u   // literal gathers read a fixed coalesced L1-resident address (timing only)
+
+#ifdef EXP_PHASES  // experiment only: per-phase shader-clock totals of each block, written over the block's first 32 output bytes
+#define PH(i) do { const uint64_t t_ = __builtin_readcyclecounter(); ph[i] += (uint32_t)(t_ - ph_last); ph_last = t_; } while (0)
+#else
+#define PH(i) do { } while (0)
+#endif
 
 struct __attribute__((aligned(16))) WaveLds {
     uint32_t ring[RING_WORDS];          // last 16 KiB of output, position p at byte p & RING_MASK
@@ -427,6 +437,10 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
     O.dict = S.dict;
     O.dict_size = S.dict_size;
     uint32_t p = 0, lp = 0, cur = 0, dead = 0, seq_base = 0;
+#ifdef EXP_PHASES
+    uint32_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t ph_last = __builtin_readcyclecounter();
+#endif
 
     while (seq_base < n_total) {
         const uint32_t s = seq_base + (uint32_t)lane;
@@ -505,6 +519,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             if (e <= k) return __shfl(err, (int)e);  // first failing sequence in stream order
         }
 
+        PH(0);
         if (k == 0u) {
             // ---- one giant sequence (> TILE_MAX bytes): the whole wave walks it in pieces
             const uint32_t gll = uni(ll), gml = uni(ml), goff = uni(off);
@@ -522,6 +537,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             p += gll + gml;
             lp += gll;
             k = 1;
+            PH(7);
         } else {
             const bool mine = (uint32_t)lane < k;
             const uint32_t tile_end = __shfl(E, (int)(k - 1u));
@@ -538,8 +554,9 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                     v4u lv = {0, 0, 0, 0};
                     uint32_t ltail = 0;
                     if (act) {
-                        lv = ld128(S.lit + lst + so);
-                        ltail = ld32(S.lit + lst + so + put_tail_index(est + so, n));
+                        const uint8_t* lsrc = (S.dbg & DBG_LIT_L1) ? S.lit + 16u * (uint32_t)lane : S.lit + lst + so;
+                        lv = ld128(lsrc);
+                        ltail = ld32(lsrc + put_tail_index(est + so, n));
                     }
                     const uint32_t lw[4] = {lv.x, lv.y, lv.z, lv.w};
                     ring_put<4>(L, est + so, n, lw, ltail, act);
@@ -553,6 +570,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                 }
                 wave_lds_fence();
             }
+            PH(1);
 
             // ---- matches. Sequence i may only copy once every earlier match of this batch
             // that overlaps its source [qa, qb) is finished: those are lanes ja..jb.
@@ -588,6 +606,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                     }
                 }
             }
+            PH(2);
             const bool overlap = off < ml;
             // lane-per-sequence in 32-byte steps works whenever a step's source is complete before
             // the step runs: no overlap at all, or a period of at least one step.
@@ -664,10 +683,53 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                 }
                 if (can) pending = false;
                 wave_lds_fence();
+#ifdef EXP_PHASES
+                if (round == 0u) PH(3); else PH(4);
+#endif
+                // Few sequences left (the typical batch has ~4 dependent ones spread over 1-2 more rounds):
+                // finish them one by one in stream order with the whole wave, a byte per lane. In order,
+                // every source is complete by construction, and one such copy costs a small fraction of
+                // a full lane-per-sequence round.
+                uint64_t pm = __ballot(pending);
+                if (pm != 0ull && __popcll(pm) <= SPARSE_MAX && !(S.dbg & DBG_NO_DEPS)) {
+                    const uint64_t longm = __ballot(is_long);
+                    while (pm) {
+                        const int j = __ffsll((unsigned long long)pm) - 1;
+                        pm &= pm - 1ull;
+                        const uint32_t jM = (uint32_t)__builtin_amdgcn_readlane((int)M, j),
+                                       jml = (uint32_t)__builtin_amdgcn_readlane((int)ml, j),
+                                       joff = (uint32_t)__builtin_amdgcn_readlane((int)off, j);
+                        const uint32_t jq = jM - joff;
+                        if (((longm >> j) & 1ull) || jq < ring_lo) {
+                            if (jq < ring_lo && !far_waited) { __builtin_amdgcn_s_waitcnt(0); far_waited = true; }
+                            coop_match<DICT>(L, O, jM, jml, joff, ring_lo, false, lane);
+                            continue;
+                        }
+                        const bool ovl = joff < jml;  // period joff: byte t comes from the first period, t mod joff
+                        const float rcp = __builtin_amdgcn_rcpf((float)joff);
+                        for (uint32_t t0 = 0; t0 < jml; t0 += 64u) {
+                            const uint32_t t = t0 + (uint32_t)lane;
+                            uint32_t r = t;
+                            if (ovl) {
+                                const uint32_t qd = (uint32_t)((float)t * rcp);
+                                r = t - qd * joff;
+                                if (r >= joff) r -= joff;
+                            }
+                            if (t < jml) ring_wr8(L, jM + t, ring_rd8(L, jq + r));
+                        }
+                        wave_lds_fence();
+                    }
+                    pending = false;
+#ifdef EXP_PHASES
+                    PH(4);
+#endif
+                    break;
+                }
             }
             p = tile_end;
             lp = __shfl(lst + ll, (int)(k - 1u));
             flush_to(L, O, p, lane);
+            PH(5);
         }
 
         // extras cursor after the k sequences consumed (the rest is re-parsed next turn)
@@ -680,7 +742,14 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
         }
         seq_base += k;
         wave_lds_fence();
+        PH(6);
     }
+#ifdef EXP_PHASES
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane < 8) ((uint32_t*)dst)[lane] = ph[0] * (lane == 0) + ph[1] * (lane == 1) + ph[2] * (lane == 2) + ph[3] * (lane == 3) +
+                                           ph[4] * (lane == 4) + ph[5] * (lane == 5) + ph[6] * (lane == 6) + ph[7] * (lane == 7);
+    return (int)p;
+#endif
     // the last chunk may be partial: it only lives in the ring so far
     if ((p & 15u) != 0u && lane == 0 && !(S.dbg & DBG_NO_STORE)) {
         const uint32_t cs = p & ~15u;
