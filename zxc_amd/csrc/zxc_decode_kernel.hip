@@ -543,34 +543,22 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             const uint32_t tile_end = __shfl(E, (int)(k - 1u));
             const uint32_t ring_lo = tile_end > RING_BYTES ? tile_end - RING_BYTES : 0u;
 
-            // ---- literals: lane-per-sequence, 16 B register steps (up to 64 B), longer runs by the whole wave
-            {
-                const bool lshort = mine && ll != 0u && ll <= 64u && !(S.dbg & DBG_NO_LIT);
-#pragma unroll 1
-                for (uint32_t so = 0; so < 64u; so += 16u) {
-                    const bool act = lshort && so < ll;
-                    if (__ballot(act) == 0ull) break;
-                    const uint32_t n = (ll - so < 16u) ? ll - so : 16u;
-                    v4u lv = {0, 0, 0, 0};
-                    uint32_t ltail = 0;
-                    if (act) {
-                        const uint8_t* lsrc = (S.dbg & DBG_LIT_L1) ? S.lit + 16u * (uint32_t)lane : S.lit + lst + so;
-                        lv = ld128(lsrc);
-                        ltail = ld32(lsrc + put_tail_index(est + so, n));
-                    }
-                    const uint32_t lw[4] = {lv.x, lv.y, lv.z, lv.w};
-                    ring_put<4>(L, est + so, n, lw, ltail, act);
+            // ---- literals, part 1: request the first 32 literal bytes of every sequence now; the loads fly
+            // while the dependency analysis below (registers and cross-lane traffic only) runs.
+            const bool lshort = mine && ll != 0u && ll <= 64u && !(S.dbg & DBG_NO_LIT);
+            const bool lact1 = lshort && ll > 16u;
+            const uint32_t ln0 = ll < 16u ? ll : 16u, ln1 = (ll - 16u < 16u) ? ll - 16u : 16u;
+            v4u lv0 = {0, 0, 0, 0}, lv1 = {0, 0, 0, 0};
+            uint32_t lt0 = 0, lt1 = 0;
+            if (lshort) {
+                const uint8_t* lsrc = (S.dbg & DBG_LIT_L1) ? S.lit + 16u * (uint32_t)lane : S.lit + lst;
+                lv0 = ld128(lsrc);
+                lt0 = ld32(lsrc + put_tail_index(est, ln0));
+                if (lact1) {
+                    lv1 = ld128(lsrc + 16u);
+                    lt1 = ld32(lsrc + 16u + put_tail_index(est + 16u, ln1));
                 }
-                uint64_t lm = __ballot(mine && ll > 64u);
-                while (lm) {
-                    const int j = __ffsll((unsigned long long)lm) - 1;
-                    lm &= lm - 1ull;
-                    const uint32_t jl = __shfl(ll, j), je = __shfl(est, j), js = __shfl(lst, j);
-                    coop_copy<DICT>(L, O, je, 0, S.lit + js, jl, 0, lane);
-                }
-                wave_lds_fence();
             }
-            PH(1);
 
             // ---- matches. Sequence i may only copy once every earlier match of this batch
             // that overlaps its source [qa, qb) is finished: those are lanes ja..jb.
@@ -607,6 +595,43 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                 }
             }
             PH(2);
+            // ---- literals, part 2: lane-per-sequence exact-length puts, 16 B per step (up to 64 B); longer
+            // runs are copied by the whole wave
+            {
+                {
+                    const uint32_t lw0[4] = {lv0.x, lv0.y, lv0.z, lv0.w};
+                    ring_put<4>(L, est, ln0, lw0, lt0, lshort);
+                }
+                if (__ballot(lact1)) {
+                    const uint32_t lw1[4] = {lv1.x, lv1.y, lv1.z, lv1.w};
+                    ring_put<4>(L, est + 16u, ln1, lw1, lt1, lact1);
+                }
+#pragma unroll 1
+                for (uint32_t so = 32u; so < 64u; so += 16u) {
+                    const bool act = lshort && so < ll;
+                    if (__ballot(act) == 0ull) break;
+                    const uint32_t n = (ll - so < 16u) ? ll - so : 16u;
+                    v4u lv = {0, 0, 0, 0};
+                    uint32_t ltail = 0;
+                    if (act) {
+                        const uint8_t* lsrc = (S.dbg & DBG_LIT_L1) ? S.lit + 16u * (uint32_t)lane : S.lit + lst + so;
+                        lv = ld128(lsrc);
+                        ltail = ld32(lsrc + put_tail_index(est + so, n));
+                    }
+                    const uint32_t lw[4] = {lv.x, lv.y, lv.z, lv.w};
+                    ring_put<4>(L, est + so, n, lw, ltail, act);
+                }
+                PH(7);  // (experiment builds: slot 7 = literal register steps, slot 1 = long literals)
+                uint64_t lm = __ballot(mine && ll > 64u);
+                while (lm) {
+                    const int j = __ffsll((unsigned long long)lm) - 1;
+                    lm &= lm - 1ull;
+                    const uint32_t jl = __shfl(ll, j), je = __shfl(est, j), js = __shfl(lst, j);
+                    coop_copy<DICT>(L, O, je, 0, S.lit + js, jl, 0, lane);
+                }
+                wave_lds_fence();
+            }
+            PH(1);
             const bool overlap = off < ml;
             // lane-per-sequence in 32-byte steps works whenever a step's source is complete before
             // the step runs: no overlap at all, or a period of at least one step.
