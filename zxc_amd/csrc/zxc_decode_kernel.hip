@@ -422,6 +422,19 @@ __device__ __forceinline__ uint32_t lanes_le(uint32_t sorted, uint32_t x) {
     return c + ((c == 63u && t63 <= x) ? 1u : 0u);
 }
 
+// Token and offset of sequence s, undecoded (GHI: the 32-bit word; GLO: token byte, offset - 1).
+__device__ __forceinline__ void load_seq_raw(const LzStreams& S, uint32_t s, uint32_t& raw_t, uint32_t& raw_o) {
+    raw_t = 0;
+    raw_o = 0;
+    if (s < S.n_seq) {
+        if (S.ghi) raw_t = ld32(S.tok + 4ull * s);
+        else {
+            raw_t = ld8(S.tok + s);
+            raw_o = S.off8 ? ld8(S.offs + s) : ld16(S.offs + 2ull * s);
+        }
+    }
+}
+
 // Executes all sequences of one block. Returns decoded size or a negative error.
 template <bool DICT>
 __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __restrict__ dst, uint32_t out_len, uint32_t cap,
@@ -442,25 +455,28 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
     uint64_t ph_last = __builtin_readcyclecounter();
 #endif
 
+    uint32_t raw_t, raw_o;
+    load_seq_raw(S, (uint32_t)lane, raw_t, raw_o);
+    uint32_t xw0 = (uint32_t)lane < S.ext_size ? ld8(S.ext + lane) : 0u;
+    uint32_t xw1 = 64u + (uint32_t)lane < S.ext_size ? ld8(S.ext + 64u + lane) : 0u;
+
     while (seq_base < n_total) {
         const uint32_t s = seq_base + (uint32_t)lane;
         const bool real = s < S.n_seq;
         const bool valid = s < n_total;
         uint32_t ll = 0, ml = 0, off = 1;
         bool escL = false, escM = false;
-        if (real) {
+        if (real) {  // (raw_t / raw_o were requested while the previous batch was being copied)
             if (S.ghi) {
-                const uint32_t w = ld32(S.tok + 4ull * s);
-                ll = w >> 24;
-                ml = (w >> 16) & 255u;
-                off = (w & 0xFFFFu) + 1u;
+                ll = raw_t >> 24;
+                ml = (raw_t >> 16) & 255u;
+                off = (raw_t & 0xFFFFu) + 1u;
                 escL = ll == 255u;
                 escM = ml == 255u;
             } else {
-                const uint32_t t = ld8(S.tok + s);
-                ll = t >> 4;
-                ml = t & 15u;
-                off = 1u + (S.off8 ? ld8(S.offs + s) : ld16(S.offs + 2ull * s));
+                ll = raw_t >> 4;
+                ml = raw_t & 15u;
+                off = 1u + raw_o;
                 escL = ll == 15u;
                 escM = ml == 15u;
             }
@@ -477,8 +493,13 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             uint32_t b0 = 0, b1 = 0;
             bool small = true;
             if (cur + nv <= S.ext_size) {
-                if (escL) { b0 = ld8(S.ext + cur + r); small = small && b0 < 0x80u; }
-                if (escM) { b1 = ld8(S.ext + cur + r2); small = small && b1 < 0x80u; }
+                // the 128 extras bytes at the cursor sit one per lane in xw0 / xw1 (requested during the
+                // previous batch): rank -> byte is a cross-lane read, not a trip to memory
+                const uint32_t x0 = __shfl(xw0, (int)(r & 63u)), y0 = __shfl(xw0, (int)(r2 & 63u));
+                uint32_t x1 = 0, y1 = 0;
+                if (nv > 64u) { x1 = __shfl(xw1, (int)(r & 63u)); y1 = __shfl(xw1, (int)(r2 & 63u)); }
+                if (escL) { b0 = r < 64u ? x0 : x1; small = small && b0 < 0x80u; }
+                if (escM) { b1 = r2 < 64u ? y0 : y1; small = small && b1 < 0x80u; }
                 fast_vi = __ballot(!small) == 0ull;
             }
             if (fast_vi) {
@@ -519,6 +540,20 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             if (e <= k) return __shfl(err, (int)e);  // first failing sequence in stream order
         }
 
+        // the next batch starts at sequence seq_base + max(k, 1): request its tokens and offsets now
+        uint32_t nraw_t, nraw_o;
+        load_seq_raw(S, seq_base + (k ? k : 1u) + (uint32_t)lane, nraw_t, nraw_o);
+        // extras cursor after the k sequences consumed (the rest is re-parsed next turn), and its window
+        if (parsed) {
+            const uint32_t kk = k ? k : 1u;
+            const uint64_t km = (kk >= 64u) ? ~0ull : ((1ull << kk) - 1ull);
+            const uint32_t used = __popcll(mL & km) + __popcll(mM & km);
+            if (fast_vi) cur += used;
+            else if (kbad < used) { dead = 1; cur = S.ext_size; }
+            else cur = uni(L.vpos[used]);
+        }
+        const uint32_t nxw0 = cur + (uint32_t)lane < S.ext_size ? ld8(S.ext + cur + lane) : 0u;
+        const uint32_t nxw1 = cur + 64u + (uint32_t)lane < S.ext_size ? ld8(S.ext + cur + 64u + lane) : 0u;
         PH(0);
         if (k == 0u) {
             // ---- one giant sequence (> TILE_MAX bytes): the whole wave walks it in pieces
@@ -757,15 +792,11 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             PH(5);
         }
 
-        // extras cursor after the k sequences consumed (the rest is re-parsed next turn)
-        if (parsed) {
-            const uint64_t km = (k >= 64u) ? ~0ull : ((1ull << k) - 1ull);
-            const uint32_t used = __popcll(mL & km) + __popcll(mM & km);
-            if (fast_vi) cur += used;
-            else if (kbad < used) { dead = 1; cur = S.ext_size; }
-            else cur = uni(L.vpos[used]);
-        }
         seq_base += k;
+        raw_t = nraw_t;
+        raw_o = nraw_o;
+        xw0 = nxw0;
+        xw1 = nxw1;
         wave_lds_fence();
         PH(6);
     }
