@@ -28,12 +28,13 @@
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
-#ifndef ENC_HBITS
-#define ENC_HBITS 13u
-#endif
-#define ENC_HSIZE (1u << ENC_HBITS)
+// Hash table size per level class (entries): the table is the LDS footprint, i.e. the occupancy:
+// 2^12 -> 8 KiB (20 waves/CU), 2^13 -> 16 KiB (10), 2^14 -> 32 KiB (5). Measured on the text corpus:
+// 66 / 42 / 24 GB/s at ratio 1.82 / 1.92 / 1.99 (reference level 3: 1.86).
 #define ENC_MARGIN 8u   // the last 8 bytes of a block never start a match (reference ZXC_LZ_SEARCH_MARGIN)
-#define ENC_EMPTY 0u    // table value 0 = empty; positions are stored +1
+// Table entries are the low 16 bits of a position: offsets are < 65536 anyway, so the candidate is
+// i - ((i - entry) & 0xFFFF); a stale or never-written entry just names some older position, and
+// every candidate is verified against the bytes. Half the LDS of 32-bit entries -> twice the waves.
 
 __device__ __forceinline__ uint32_t e_ld8(const uint8_t* p) { return *p; }
 __device__ __forceinline__ uint64_t e_ld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
@@ -99,11 +100,12 @@ __device__ void wave_move_down(uint8_t* dst, const uint8_t* src, uint32_t n, int
 
 // Slot layout while encoding (stride = 2*block_size + 512 bytes per block):
 //   [0,8) block header | [8,20) GLO header | literals ... | ... staging: tokens, offsets, extras
-extern "C" __global__ void __launch_bounds__(64)
-zxc_encode_blocks_kernel(const uint8_t* __restrict__ src, uint64_t src_size, uint32_t block_size,
-                         uint8_t* __restrict__ slots, uint32_t slot_stride, uint32_t* __restrict__ sizes,
-                         uint32_t n_blocks, uint32_t with_checksum) {
-    __shared__ uint32_t ht[ENC_HSIZE];
+template <uint32_t ENC_HBITS>
+__device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src, uint64_t src_size, uint32_t block_size,
+                                                 uint8_t* __restrict__ slots, uint32_t slot_stride,
+                                                 uint32_t* __restrict__ sizes, uint32_t n_blocks, uint32_t with_checksum) {
+    constexpr uint32_t ENC_HSIZE = 1u << ENC_HBITS;
+    __shared__ uint16_t ht[ENC_HSIZE];
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) return;
@@ -118,7 +120,7 @@ zxc_encode_blocks_kernel(const uint8_t* __restrict__ src, uint64_t src_size, uin
     uint8_t* off_st = tok_st + max_seq;       // u16 per sequence
     uint8_t* ext_st = off_st + 2u * max_seq;  // <= 6 bytes per sequence would not fit worst case; bounded below
 
-    for (uint32_t i = lane; i < ENC_HSIZE; i += 64u) ht[i] = ENC_EMPTY;
+    for (uint32_t i = lane; i < ENC_HSIZE / 2u; i += 64u) ((uint32_t*)ht)[i] = 0u;
     __syncthreads();
 
     uint32_t seq_count = 0, lit_count = 0, ext_count = 0, max_off = 0;
@@ -129,6 +131,8 @@ zxc_encode_blocks_kernel(const uint8_t* __restrict__ src, uint64_t src_size, uin
     bool overflow = false;
 
     uint32_t c0 = 0;
+    uint64_t v_next = (uint32_t)lane < limit ? e_ld64(in + lane) : 0ull;  // 8 bytes at every position of the next chunk
+    uint32_t c_next = 0;
     while (c0 < n) {
         const uint32_t i = c0 + (uint32_t)lane;
         // ---- 1. candidate + verified length for every position of the chunk
@@ -136,14 +140,19 @@ zxc_encode_blocks_kernel(const uint8_t* __restrict__ src, uint64_t src_size, uin
         uint64_t v = 0;
         const bool can = i < limit;
         uint32_t h = 0;
+        if (c_next != c0 && can) v_next = e_ld64(in + i);  // (a long match skipped ahead: the prefetch was for another chunk)
+        {   // request the following chunk's bytes now; they arrive while this chunk is matched, parsed and emitted
+            v = v_next;
+            c_next = c0 + 64u;
+            const uint32_t i2 = c_next + (uint32_t)lane;
+            if (i2 < limit) v_next = e_ld64(in + i2);
+        }
         if (can) {
-            v = e_ld64(in + i);
             h = (uint32_t)(((v & 0xFFFFFFFFFFull) * 0x9E3779B185EBCA87ull) >> (64u - ENC_HBITS));
-            const uint32_t t = ht[h];
-            if (t != ENC_EMPTY) {
-                cpos = t - 1u;
-                const uint32_t dist = i - cpos;
-                if (cpos < i && dist <= 65535u) {
+            const uint32_t dist = (i - (uint32_t)ht[h]) & 0xFFFFu;
+            {
+                cpos = i - dist;
+                if (dist != 0u && dist <= i) {
                     const uint64_t x = v ^ e_ld64(in + cpos);
                     if (x == 0) {
                         len = 8;
@@ -162,22 +171,24 @@ zxc_encode_blocks_kernel(const uint8_t* __restrict__ src, uint64_t src_size, uin
             }
         }
         // ---- 2. publish this chunk's positions (most recent wins)
-        if (can) atomicMax(&ht[h], i + 1u);
+        if (can) ht[h] = (uint16_t)i;
         __syncthreads();
 
         // ---- 3. scalar parse of the chunk
         uint64_t sel = 0;
         uint32_t p = pos > c0 ? pos - c0 : 0u;
-        while (p < 64u && c0 + p < n) {
+        const uint64_t has = __ballot(len >= 5u);  // positions where a match starts
+        const uint32_t pend = (n - c0 < 64u) ? n - c0 : 64u;
+        while (p < pend) {
+            const uint64_t ahead = has >> p;
+            if (ahead == 0ull) { p = pend; break; }  // nothing left in this chunk: all literals
+            p += (uint32_t)__builtin_ctzll(ahead);
+            if (p >= pend) { p = pend; break; }
             const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)p);
-            if (L >= 5u) {
-                const uint32_t L1 = (p + 1u < 64u) ? (uint32_t)__builtin_amdgcn_readlane((int)len, (int)(p + 1u)) : 0u;
-                if (L1 > L + 1u) { p++; continue; }  // lazy: a clearly longer match starts one byte later
-                sel |= 1ull << p;
-                p += L;
-            } else {
-                p++;
-            }
+            const uint32_t L1 = (p + 1u < 64u) ? (uint32_t)__builtin_amdgcn_readlane((int)len, (int)(p + 1u)) : 0u;
+            if (L1 > L + 1u) { p++; continue; }  // lazy: a clearly longer match starts one byte later
+            sel |= 1ull << p;
+            p += L;
         }
         const uint32_t next_pos = c0 + p;
 
@@ -299,6 +310,16 @@ zxc_encode_blocks_kernel(const uint8_t* __restrict__ src, uint64_t src_size, uin
     }
     if (lane == 0) sizes[b] = total;
 }
+
+#define ZXC_ENCODE_ENTRY(name, bits)                                                                                   \
+    extern "C" __global__ void __launch_bounds__(64) name(                                                             \
+        const uint8_t* __restrict__ src, uint64_t src_size, uint32_t block_size, uint8_t* __restrict__ slots,          \
+        uint32_t slot_stride, uint32_t* __restrict__ sizes, uint32_t n_blocks, uint32_t with_checksum) {               \
+        encode_one_block<bits>(src, src_size, block_size, slots, slot_stride, sizes, n_blocks, with_checksum);         \
+    }
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_h12, 12u)  // levels 1-2
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_h13, 13u)  // levels 3-4
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_h14, 14u)  // levels 5-7
 
 // Compaction: block b's bytes [slot, slot+sizes[b]) -> out + offsets[b] (+ optional 4-byte trailer gap).
 extern "C" __global__ void __launch_bounds__(64)
