@@ -131,21 +131,23 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     bool overflow = false;
 
     uint32_t c0 = 0;
-    uint64_t v_next = (uint32_t)lane < limit ? e_ld64(in + lane) : 0ull;  // 8 bytes at every position of the next chunk
+    v4u v_next = {0, 0, 0, 0};  // 16 bytes at every position of the next chunk
+    if ((uint32_t)lane < limit) v_next = e_ld128(in + lane);
     uint32_t c_next = 0;
     while (c0 < n) {
         const uint32_t i = c0 + (uint32_t)lane;
         // ---- 1. candidate + verified length for every position of the chunk
         uint32_t len = 0, cpos = 0;
-        uint64_t v = 0;
+        uint64_t v = 0, vh = 0;
         const bool can = i < limit;
         uint32_t h = 0;
-        if (c_next != c0 && can) v_next = e_ld64(in + i);  // (a long match skipped ahead: the prefetch was for another chunk)
+        if (c_next != c0 && can) v_next = e_ld128(in + i);  // (a long match skipped ahead: the prefetch was for another chunk)
         {   // request the following chunk's bytes now; they arrive while this chunk is matched, parsed and emitted
-            v = v_next;
+            v = (uint64_t)v_next.x | ((uint64_t)v_next.y << 32);
+            vh = (uint64_t)v_next.z | ((uint64_t)v_next.w << 32);
             c_next = c0 + 64u;
             const uint32_t i2 = c_next + (uint32_t)lane;
-            if (i2 < limit) v_next = e_ld64(in + i2);
+            if (i2 < limit) v_next = e_ld128(in + i2);
         }
         if (can) {
             h = (uint32_t)(((v & 0xFFFFFFFFFFull) * 0x9E3779B185EBCA87ull) >> (64u - ENC_HBITS));
@@ -153,9 +155,14 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             {
                 cpos = i - dist;
                 if (dist != 0u && dist <= i) {
-                    const uint64_t x = v ^ e_ld64(in + cpos);
-                    if (x == 0) {
-                        len = 8;
+                    // 16 bytes of both sides in one round trip: most matches end inside them
+                    const v4u cv = e_ld128(in + cpos);
+                    const uint64_t x = v ^ ((uint64_t)cv.x | ((uint64_t)cv.y << 32));
+                    const uint64_t xh = vh ^ ((uint64_t)cv.z | ((uint64_t)cv.w << 32));
+                    if (x == 0 && xh != 0) {
+                        len = 8u + (uint32_t)(__builtin_ctzll(xh) >> 3);
+                    } else if (x == 0) {
+                        len = 16;
                         while (i + len + 8u <= n) {  // extend, 8 bytes at a time
                             const uint64_t y = e_ld64(in + i + len) ^ e_ld64(in + cpos + len);
                             if (y) { len += (uint32_t)(__builtin_ctzll(y) >> 3); break; }
