@@ -211,6 +211,36 @@ __device__ __forceinline__ v4u far_rd128(const Out& O, uint32_t q) {
     r.w = __builtin_amdgcn_alignbyte(g4, g.w, sh);
     return r;
 }
+// The same in two halves, so that the loads can be requested long before their bytes are needed:
+// far_issue() only starts the (dword-aligned) loads, far_take() shifts them into place.
+struct FarRaw { v4u a, b; uint32_t c; };
+__device__ __forceinline__ FarRaw far_issue(const Out& O, uint32_t q, bool second) {
+    FarRaw r;
+    r.a = (v4u){0, 0, 0, 0};
+    r.b = (v4u){0, 0, 0, 0};
+    r.c = 0;
+    if ((O.dbg & DBG_NO_FAR) || q + 36u > O.out_pad) return r;
+    const uint8_t* p = O.dst + (q & ~3u);
+    r.a = __builtin_nontemporal_load((const v4u*)p);
+    if (second) {
+        r.b = __builtin_nontemporal_load((const v4u*)(p + 16));
+        r.c = __builtin_nontemporal_load((const uint32_t*)(p + 32));
+    } else {
+        r.b.x = __builtin_nontemporal_load((const uint32_t*)(p + 16));
+    }
+    return r;
+}
+__device__ __forceinline__ void far_take(const FarRaw& r, uint32_t q, v4u& lo16, v4u& hi16) {
+    const uint32_t sh = q & 3u;
+    lo16.x = __builtin_amdgcn_alignbyte(r.a.y, r.a.x, sh);
+    lo16.y = __builtin_amdgcn_alignbyte(r.a.z, r.a.y, sh);
+    lo16.z = __builtin_amdgcn_alignbyte(r.a.w, r.a.z, sh);
+    lo16.w = __builtin_amdgcn_alignbyte(r.b.x, r.a.w, sh);
+    hi16.x = __builtin_amdgcn_alignbyte(r.b.y, r.b.x, sh);
+    hi16.y = __builtin_amdgcn_alignbyte(r.b.z, r.b.y, sh);
+    hi16.z = __builtin_amdgcn_alignbyte(r.b.w, r.b.z, sh);
+    hi16.w = __builtin_amdgcn_alignbyte(r.c, r.b.w, sh);
+}
 __device__ __forceinline__ uint32_t far_rd8(const Out& O, uint32_t q) {
     if ((O.dbg & DBG_NO_FAR) || q >= O.out_pad) return 0;
     return __builtin_nontemporal_load(O.dst + q);
@@ -629,6 +659,28 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                     }
                 }
             }
+            const bool overlap = off < ml;
+            // lane-per-sequence in 32-byte steps works whenever a step's source is complete before
+            // the step runs: no overlap at all, or a period of at least one step.
+            const bool stepable = !fromdict && ml <= MED_MAX && (!overlap || off >= SHORT_MAX);
+            const bool bytewise = !fromdict && overlap && off < SHORT_MAX && ml <= SHORT_MAX;
+            const bool is_long = !stepable && !bytewise;
+            bool far_waited = false;
+            // Sources older than the ring come back from the block's own output through L2 (~700 clk). Such a
+            // lane depends on nothing in this batch, so its first 32 bytes are requested here: the literal
+            // loads above are older (VMEM returns in order), so waiting for them below does not wait for
+            // these, and the literal puts run under the round trip.
+            const bool pf = pending && need == 0ull && stepable && qsrc < ring_lo && qsrc + 36u <= O.out_pad &&
+                            !(S.dbg & DBG_NO_SHORT);
+            FarRaw fr;
+            fr.a = (v4u){0, 0, 0, 0};
+            fr.b = (v4u){0, 0, 0, 0};
+            fr.c = 0;
+            // (unconditional wait: the literal data is needed next anyway, and with every older access known to
+            // be complete on both paths the compiler does not force these loads to finish before the literal puts)
+            __builtin_amdgcn_s_waitcnt(0);  // also: the flush stores that wrote those bytes have landed
+            far_waited = true;
+            if (pf) fr = far_issue(O, qsrc, ml > 16u);
             PH(2);
             // ---- literals, part 2: lane-per-sequence exact-length puts, 16 B per step (up to 64 B); longer
             // runs are copied by the whole wave
@@ -667,13 +719,6 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                 wave_lds_fence();
             }
             PH(1);
-            const bool overlap = off < ml;
-            // lane-per-sequence in 32-byte steps works whenever a step's source is complete before
-            // the step runs: no overlap at all, or a period of at least one step.
-            const bool stepable = !fromdict && ml <= MED_MAX && (!overlap || off >= SHORT_MAX);
-            const bool bytewise = !fromdict && overlap && off < SHORT_MAX && ml <= SHORT_MAX;
-            const bool is_long = !stepable && !bytewise;
-            bool far_waited = false;
             for (uint32_t round = 0;; round++) {
                 const uint64_t dm = __ballot(!pending);
                 if (dm == ~0ull) break;
@@ -689,9 +734,11 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                         if (__ballot(act) == 0ull) break;
                         const uint32_t n = (ml - so < SHORT_MAX) ? ml - so : SHORT_MAX;
                         const uint32_t q = qsrc + so, d = M + so;
-                        const bool isfar = act && q < ring_lo;
+                        const bool usepf = act && so == 0u && pf;  // requested before the literal puts
+                        const bool isfar = act && q < ring_lo && !usepf;
                         const uint32_t ts = put_tail_index(d, n);
                         v4u s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+                        if (usepf) far_take(fr, q, s0, s1);
                         if (__ballot(isfar)) {
                             if (!far_waited) { __builtin_amdgcn_s_waitcnt(0); far_waited = true; }
                             if (isfar) {
@@ -699,7 +746,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                                 if (n > 16u) s1 = far_rd128(O, q + 16u);
                             }
                         }
-                        if (act && !isfar) {
+                        if (act && !isfar && !usepf) {
                             s0 = ring_rd128(L, q);
                             if (n > 16u) s1 = ring_rd128(L, q + 16u);
                         }
