@@ -62,6 +62,7 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 #define DBG_NO_LONG 16u
 #define DBG_NO_DEPS 32u
 #define DBG_NO_SHORT 64u
+#define DBG_FAR_L2 256u   // far reads all hit one small region (timing only: cost without the HBM round trip)
 #define DBG_LIT_L1 128u   // literal gathers read a fixed coalesced L1-resident address (timing only)
 
 #ifdef EXP_PHASES  // experiment only: per-phase shader-clock totals of each block, written over the block's first 32 output bytes
@@ -200,6 +201,7 @@ struct Out {
 __device__ __forceinline__ v4u far_rd128(const Out& O, uint32_t q) {
     v4u z = {0, 0, 0, 0};
     if ((O.dbg & DBG_NO_FAR) || q + 20u > O.out_pad) return z;  // 2nd case: only a malformed, oversize block
+    if (O.dbg & DBG_FAR_L2) q &= 1023u;
     const uint8_t* a = O.dst + (q & ~3u);
     const v4u g = __builtin_nontemporal_load((const v4u*)a);
     const uint32_t g4 = __builtin_nontemporal_load((const uint32_t*)(a + 16));
@@ -220,6 +222,7 @@ __device__ __forceinline__ FarRaw far_issue(const Out& O, uint32_t q, bool secon
     r.b = (v4u){0, 0, 0, 0};
     r.c = 0;
     if ((O.dbg & DBG_NO_FAR) || q + 36u > O.out_pad) return r;
+    if (O.dbg & DBG_FAR_L2) q &= 1023u;
     const uint8_t* p = O.dst + (q & ~3u);
     r.a = __builtin_nontemporal_load((const v4u*)p);
     if (second) {
