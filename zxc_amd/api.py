@@ -192,3 +192,68 @@ def decode_blocks_device(d_comp, d_jobs, n_jobs, d_out, d_status, block_size, ve
                                                C.c_void_p(stream))
     if rc < 0:
         raise ZxcError(rc, "zxc_mi355x_decode_blocks_device")
+
+
+# ---- FILE* callers (include/zxc_stream.h). ctypes has no FILE*, so the C library's fopen/fclose are used.
+_LIBC = None
+
+
+def _libc():
+    global _LIBC
+    if _LIBC is None:
+        L = C.CDLL(None)
+        L.fopen.restype = C.c_void_p
+        L.fopen.argtypes = [C.c_char_p, C.c_char_p]
+        L.fclose.argtypes = [C.c_void_p]
+        _LIBC = L
+    return _LIBC
+
+
+class _File:
+    def __init__(self, path, mode):
+        self.fp = _libc().fopen(os.fsencode(path), mode.encode())
+        if not self.fp:
+            raise OSError(f"fopen({path!r}, {mode!r}) failed")
+
+    def __enter__(self):
+        return self.fp
+
+    def __exit__(self, *a):
+        _libc().fclose(self.fp)
+
+
+def _bind_stream(L):
+    L.zxc_stream_compress.restype = C.c_int64
+    L.zxc_stream_compress.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_CompressOpts)]
+    L.zxc_stream_decompress.restype = C.c_int64
+    L.zxc_stream_decompress.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_DecompressOpts)]
+    L.zxc_stream_get_decompressed_size.restype = C.c_int64
+    L.zxc_stream_get_decompressed_size.argtypes = [C.c_void_p]
+    L.zxc_seekable_open_file.restype = C.c_void_p
+    L.zxc_seekable_open_file.argtypes = [C.c_void_p]
+    return L
+
+
+def stream_compress(src_path, dst_path, level=3, block_size=65536, seekable=True, checksum=False, library=None):
+    """zxc_stream_compress(): file in, archive out. Returns bytes written or a negative zxc_error_t."""
+    L = _bind_stream(library or lib())
+    o = _CompressOpts(level=level, block_size=block_size, seekable=int(seekable), checksum_enabled=int(checksum))
+    with _File(src_path, "rb") as fi, _File(dst_path, "wb") as fo:
+        return int(L.zxc_stream_compress(fi, fo, C.byref(o)))
+
+
+def stream_decompress(src_path, dst_path, checksum=False, library=None):
+    """zxc_stream_decompress(): archive in, file out (dst_path None = integrity check only)."""
+    L = _bind_stream(library or lib())
+    o = _DecompressOpts(checksum_enabled=int(checksum))
+    with _File(src_path, "rb") as fi:
+        if dst_path is None:
+            return int(L.zxc_stream_decompress(fi, None, C.byref(o)))
+        with _File(dst_path, "wb") as fo:
+            return int(L.zxc_stream_decompress(fi, fo, C.byref(o)))
+
+
+def stream_get_decompressed_size(path, library=None):
+    L = _bind_stream(library or lib())
+    with _File(path, "rb") as fi:
+        return int(L.zxc_stream_get_decompressed_size(fi))

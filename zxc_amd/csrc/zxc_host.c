@@ -725,3 +725,5 @@ int64_t zxc_seekable_decompress_range_mt(zxc_seekable* s, void* dst, const size_
     (void)n_threads; /* block-level parallelism is the GPU launch's; CPU threads add nothing */
     return zxc_seekable_decompress_range(s, dst, dst_capacity, offset, len);
 }
+
+#include "zxc_stream_host.inc"
