@@ -111,9 +111,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # ZXC_BENCH_BACKEND=gloo + ZXC_BENCH_DEVICE=0 lets a 1-GPU box rehearse the N-rank path (all ranks on one GPU)
+    backend = os.environ.get("ZXC_BENCH_BACKEND", "nccl")
+    if "ZXC_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["ZXC_BENCH_DEVICE"])
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local)
     zxc_amd.lib().zxc_mi355x_set_device(local)
     dev = torch.device("cuda", local)
@@ -173,7 +180,7 @@ def main():
     wall = time.perf_counter() - t0
     kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
