@@ -224,18 +224,14 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             if (ll >= 15u) { put_varint(e, ll - 15u); e += varint_len(ll - 15u); }
             if (mlm >= 15u) put_varint(e, mlm - 15u);
         }
-        const uint32_t moff = e_wave_max(issel ? off : 0u);
-        max_off = moff > max_off ? moff : max_off;
-        // coverage: positions of this chunk inside a selected match (or inside the carried one)
+        // only the 8-bit / 16-bit offset decision needs the maximum: one ballot instead of a wave reduction
+        if (__ballot(issel && off > 256u)) max_off = 65535u;
+        else if (sel && max_off == 0u) max_off = 1u;
+        // coverage: selected matches are disjoint and in order, so a position is covered exactly when it lies
+        // before the end of the last selected match at or below it (or of the match carried into the chunk)
         uint32_t cover_until = pos;  // positions < pos are covered by a match that started earlier
         {
-            // running max of match ends over selected lanes below or at me
-            uint32_t endv = issel ? i + len : 0u;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t t = __shfl_up(endv, d);
-                if (lane >= d) endv = t > endv ? t : endv;
-            }
+            const uint32_t endv = issel ? i + len : (below ? prev_end : 0u);
             cover_until = endv > cover_until ? endv : cover_until;
         }
         // literal = in range, not inside a match, and already passed by the parse
