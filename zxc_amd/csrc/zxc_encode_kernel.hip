@@ -237,7 +237,9 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         // literal = in range, not inside a match, and already passed by the parse
         const bool islit = i < n && i >= cover_until && i < next_pos;
         const uint64_t litmask = __ballot(islit);
-        if (islit) lit_out[lit_count + __popcll(litmask & lt_mask)] = (uint8_t)e_ld8(in + i);
+        // (the byte is already here: low byte of the 16 fetched for this position; only the block's last 16
+        // positions, which never start a match, were not fetched)
+        if (islit) lit_out[lit_count + __popcll(litmask & lt_mask)] = can ? (uint8_t)v : (uint8_t)e_ld8(in + i);
         lit_count += __popcll(litmask);
         seq_count += nsel;
         ext_count += etot;
