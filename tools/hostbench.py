@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rates of the host-buffer API (zxc_decompress / zxc_compress on pageable memory):
+reported in DESIGN.md next to the HBM-resident number, never as the bench value."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import zxc_amd, bench
+data, comp, prep = bench.build_workload(64 << 20, 3, 65536)
+zxc_amd.decompress(comp)  # warm-up (context, scratch)
+best = 1e9
+for _ in range(5):
+    t = time.perf_counter(); rc, out = zxc_amd.decompress(comp); dt = time.perf_counter() - t; best = min(best, dt)
+assert out == data
+print(f"zxc_decompress host->host, {len(data)>>20} MiB: {len(data)/best/1e9:.2f} GB/s decoded ({best*1e3:.1f} ms)")
+best = 1e9
+for _ in range(3):
+    t = time.perf_counter(); c = zxc_amd.compress(data, 3, 65536, True); dt = time.perf_counter() - t; best = min(best, dt)
+print(f"zxc_compress host->host level 3: {len(data)/best/1e9:.2f} GB/s source ({best*1e3:.1f} ms), ratio {len(data)/len(c):.3f}")
