@@ -9,9 +9,16 @@ data, comp, prep = bench.build_workload(64 << 20, 3, 65536)
 zxc_amd.decompress(comp)  # warm-up (context, scratch)
 best = 1e9
 for _ in range(5):
-    t = time.perf_counter(); rc, out = zxc_amd.decompress(comp); dt = time.perf_counter() - t; best = min(best, dt)
+    t = time.perf_counter(); out = zxc_amd.decompress(comp); dt = time.perf_counter() - t; best = min(best, dt)
 assert out == data
 print(f"zxc_decompress host->host, {len(data)>>20} MiB: {len(data)/best/1e9:.2f} GB/s decoded ({best*1e3:.1f} ms)")
+import ctypes as C
+L = zxc_amd.lib(); dst = C.create_string_buffer(len(data))
+best = 1e9
+for _ in range(5):
+    t = time.perf_counter(); rc = L.zxc_decompress(comp, len(comp), dst, len(data), None); dt = time.perf_counter() - t; best = min(best, dt)
+assert rc == len(data)
+print(f"  C call only (caller-owned buffers): {len(data)/best/1e9:.2f} GB/s decoded ({best*1e3:.1f} ms)")
 best = 1e9
 for _ in range(3):
     t = time.perf_counter(); c = zxc_amd.compress(data, 3, 65536, True); dt = time.perf_counter() - t; best = min(best, dt)
