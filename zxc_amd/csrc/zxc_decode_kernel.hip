@@ -4,23 +4,27 @@
 // (reference: zxc_decompress_chunk_wrapper, src/lib/zxc_decompress.c:1646-1695;
 // GLO body :847-1209, GHI body :1231-1469). Nothing here is a translation of the
 // CPU loop (one sequence at a time, wild 16/32-byte copies). Per block the wave
-//   1. parses 64 sequences per step, one per lane: token nibbles / GHI words,
-//      varint escapes located with ballot + prefix popcount, varint boundaries
-//      found by a wave-wide scan of 3-state transition maps (the prefix varint is
-//      a 3-state automaton), output/literal cursors by wave prefix sums;
-//   2. copies literals and short matches sequence-per-lane in lockstep into an
-//      LDS ring that holds the last RING_BYTES (4 KiB) of output (the sliding window): the
-//      loop counter is wave-uniform, so every step is one LDS read + one LDS write
-//      instruction for all 64 sequences; source dwords are built from aligned LDS
-//      reads + v_alignbyte (unaligned DS accesses replay on gfx950);
-//   3. orders matches that depend on other matches of the same batch with exact
-//      dependency masks checked against a ballot of finished lanes (no barrier);
-//      matches older than the ring read the block's own output back from L2;
-//   4. long copies (> 32 B) are done by the whole wave, 16 B per lane; overlapping
-//      matches (offset < length) become a series of non-overlapping copies whose
-//      distance doubles (a period stays a period), so runs need no byte loop;
+//   1. parses 64 sequences per batch, one per lane: token nibbles / GHI words and the window of
+//      the extras stream were requested during the previous batch; varint escapes located with
+//      ballot + prefix popcount, single-byte varints read cross-lane from the window, longer ones
+//      by a wave-wide scan of 3-state transition maps (the prefix varint is a 3-state automaton);
+//      output / literal cursors by DPP prefix sums;
+//   2. requests the literals, runs the dependency analysis while they fly, requests the sources
+//      that are older than the ring, then puts literals and matches sequence-per-lane into an LDS
+//      ring that holds the last RING_BYTES (4 KiB) of output (the sliding window): straight-line
+//      exact-length register puts (aligned LDS accesses + v_alignbyte; unaligned DS accesses are
+//      8x slower on gfx950);
+//   3. orders matches that depend on other matches of the same batch with exact dependency masks
+//      checked against a ballot of finished lanes (no barrier); the last few dependent ones are
+//      finished one by one, in stream order, by the whole wave;
+//   4. long copies are done by the whole wave, 16 B per lane; overlapping matches (offset <
+//      length) become a series of non-overlapping copies whose distance doubles (a period stays
+//      a period), so runs need no byte loop;
 //   5. streams finished 16-byte chunks from the ring to HBM, one coalesced
 //      global_store_dwordx4 per lane.
+// RLE and PivCo (Huffman) literal / token sections are expanded first into a scratch slot
+// (rle_expand below, zxc_pivco.inc); checksums by zxc_rapidhash.inc; a dictionary prefix is a
+// template variant. Launch order: heaviest blocks first (zxc_order_* kernels at the end).
 // Integer byte work: no MFMA. Bound: HBM (compressed bytes in + decoded bytes out).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
