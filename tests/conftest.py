@@ -10,6 +10,14 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Tests that hand torch streams / device tensors to the library need ONE HIP runtime in the process: torch
+# ships its own libamdhip64, and whichever copy is loaded first is the one both sides must share. Loading
+# torch before libzxc_mi355x.so (as bench.py does) makes that torch's.
+try:
+    import torch  # noqa: F401
+except Exception:  # torch is plumbing for a few tests only
+    torch = None
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

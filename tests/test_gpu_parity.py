@@ -146,3 +146,37 @@ def test_checksum_verification(gpu, oracle, manifest):
     m[-1] ^= 0x40  # global hash in the footer
     assert gpu.decompress(bytes(m), size, checksum=True, raise_on_error=False)[0] == -7
     assert gpu.decompress(bytes(m), size, checksum=False) is not None
+
+
+def test_concurrent_launches_on_two_streams(gpu, ref):
+    """Two streams decode level-6 archives (scratch slots, PivCo) and long launches (ordered dispatch) at the
+    same time: the lock-free scratch pool and the per-stream order buffers must keep them apart."""
+    import torch
+    from zxc_amd import corpus
+    dev = torch.device("cuda", 0)
+    data = corpus.synth_silesia(24 << 20, seed=9)
+    work = []
+    for level, bs in ((6, 65536), (3, 4096)):  # 384 PivCo blocks; 6144 blocks (> one round of workgroups)
+        comp = ref.compress(data, level, bs, True, False)
+        s = gpu.Seekable(comp)
+        jobs = s.plan()
+        d_comp = torch.frombuffer(bytearray(comp) + bytearray(64), dtype=torch.uint8).to(dev)
+        d_jobs = torch.frombuffer(bytearray(jobs.tobytes()), dtype=torch.uint8).to(dev)
+        d_out = torch.zeros(len(data) + 256, dtype=torch.uint8, device=dev)
+        d_st = torch.zeros(jobs.size, dtype=torch.int32, device=dev)
+        work.append((bs, jobs, d_comp, d_jobs, d_out, d_st, torch.cuda.Stream(device=dev)))
+        s.close()
+    want = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+    torch.cuda.synchronize()
+    for _ in range(6):
+        for bs, jobs, d_comp, d_jobs, d_out, d_st, st in work:
+            d_out.zero_()
+        torch.cuda.synchronize()
+        for rep in range(3):
+            for bs, jobs, d_comp, d_jobs, d_out, d_st, st in work:
+                gpu.decode_blocks_device(d_comp.data_ptr(), d_jobs.data_ptr(), jobs.size, d_out.data_ptr(),
+                                         d_st.data_ptr(), bs, False, st.cuda_stream)
+        torch.cuda.synchronize()
+        for bs, jobs, d_comp, d_jobs, d_out, d_st, st in work:
+            assert (d_st.cpu().numpy() == jobs["out_len"].astype(np.int32)).all(), bs
+            assert torch.equal(d_out[:len(data)], want), bs
