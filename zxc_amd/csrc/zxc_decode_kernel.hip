@@ -1075,7 +1075,7 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
 }
 
 #ifndef WAVES_PER_SIMD
-#define WAVES_PER_SIMD 1
+#define WAVES_PER_SIMD 5   // 20 workgroups per CU fit the LDS (7.5 KiB each): keep everyone, callees included, within 96 VGPRs
 #endif
 template <bool DICT>
 __device__ __forceinline__ void decode_one_block(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs,
