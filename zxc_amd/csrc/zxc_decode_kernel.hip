@@ -40,6 +40,9 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 #define RING_MASK (RING_BYTES - 1u)
 #define RING_WORDS (RING_BYTES / 4u)
 #define RING_WMASK (RING_WORDS - 1u)
+#ifndef REDIRECT_PASSES
+#define REDIRECT_PASSES 2   // chained containment levels resolved before round 0 (A/B: 0: -6 %, 1: -2 %, 2: best, 3: -1 %)
+#endif
 #ifndef SPARSE_MAX
 #define SPARSE_MAX 8   // at most this many unfinished sequences after a round: finish them one by one
 #endif
@@ -665,7 +668,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                 const uint32_t jM = __shfl(M, jl), jE = __shfl(E, jl), jo = __shfl(off, jl);
                 const bool simple = need != 0ull && !fromdict && jbp == ja + 1u && off >= ml && qa >= jM && qb <= jE && qb - jM <= jo;
 #pragma unroll
-                for (int pass = 0; pass < 3; pass++) {
+                for (int pass = 0; pass < REDIRECT_PASSES; pass++) {
                     const uint32_t jready = __shfl((uint32_t)(need == 0ull), jl);
                     const uint32_t jq = __shfl(qsrc, jl);
                     const uint32_t nq = jq + (qa - jM);
