@@ -9,7 +9,7 @@ import zxc_amd, oracle_py
 from zxc_amd import corpus
 ref = oracle_py.Ref()
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-classes = {c: corpus._GEN[c](mib << 20, corpus._rng(7, 3)).tobytes() for c in corpus._GEN}
+classes = {c: corpus._GEN[c](mib << 20, corpus._rng(int(os.environ.get("SWEEP_SEED", "7")), 3)).tobytes() for c in corpus._GEN}
 classes["zeros"] = bytes(mib << 20)
 classes["random"] = np.random.default_rng(5).integers(0, 256, mib << 20, dtype=np.uint8).tobytes()
 classes["mix"] = corpus.synth_silesia(mib << 20, seed=11)
