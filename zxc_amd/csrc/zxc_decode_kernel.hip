@@ -75,6 +75,9 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 #define DBG_NO_LONG 16u
 #define DBG_NO_DEPS 32u
 #define DBG_NO_SHORT 64u
+#define DBG_NO_SEQ 512u      // stop after the literal / token sections are expanded (timing only)
+#define DBG_PIV_NO_P2 1024u  // PivCo: skip the bottom-up merges (timing only)
+#define DBG_PIV_NO_P1 2048u  // PivCo: skip everything after the tree set-up (timing only)
 #define DBG_FAR_L2 256u   // far reads all hit one small region (timing only: cost without the HBM round trip)
 #define DBG_LIT_L1 128u   // literal gathers read a fixed coalesced L1-resident address (timing only)
 
@@ -1044,7 +1047,7 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
             if (S.n_lit > block_size) return E_CORRUPT;
             uint8_t* scratch = scratch_acquire(pool, lane);
             const int rc = pivco_decode(pdata, lit_comp, scratch, S.n_lit, scratch + block_size + 64u,
-                                  reinterpret_cast<PivLds&>(L), lane, enc_lit == 3u ? dict_huf : nullptr);
+                                  reinterpret_cast<PivLds&>(L), lane, enc_lit == 3u ? dict_huf : nullptr, dbg);
             if (rc != 0) return rc;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // literals are read back with L1-cached loads
@@ -1071,7 +1074,7 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
         uint8_t* scratch = scratch_acquire(pool, lane);
         uint8_t* tokbuf = scratch + 2u * (block_size + 64u);
         const int rc = pivco_decode(S.tok, tok_comp, tokbuf, S.n_seq, scratch + block_size + 64u,
-                                    reinterpret_cast<PivLds&>(L), lane, nullptr);
+                                    reinterpret_cast<PivLds&>(L), lane, nullptr, dbg);
         if (rc != 0) return rc;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1083,6 +1086,7 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
     S.off8 = enc_off;
     S.ext = S.offs + sz_off;
     S.ext_size = avail - (uint32_t)consumed;
+    if (dbg & DBG_NO_SEQ) return (int)out_len;
     return run_sequences<DICT>(S, dst, out_len, cap, L, lane);
 }
 
