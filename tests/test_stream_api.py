@@ -21,6 +21,17 @@ def test_stream_size_probe_needs_no_gpu(product, manifest, tmp_path):
     assert product.api.stream_get_decompressed_size(str(tiny)) == -3  # SRC_TOO_SMALL
 
 
+def test_stream_fails_loudly_without_gpu(product, tmp_path):
+    """No CPU codec behind the FILE* callers either: without a HIP device they return GPU_UNAVAILABLE (-100)."""
+    if product.lib().zxc_mi355x_device_count() > 0:
+        pytest.skip("a GPU is present")
+    p = os.path.join(GOLDEN, "synth", "lorem_100k_l3_b64k.zxc")
+    assert product.api.stream_decompress(p, str(tmp_path / "o.bin")) == -100
+    src = tmp_path / "in.bin"
+    src.write_bytes(b"hello world " * 1000)
+    assert product.api.stream_compress(str(src), str(tmp_path / "a.zxc")) == -100
+
+
 @pytest.mark.gpu
 def test_stream_decompress_matches_inputs(product, manifest, synth_inputs, tmp_path, monkeypatch):
     monkeypatch.setenv("ZXC_STREAM_BATCH_BYTES", str(256 << 10))  # several launches per file
