@@ -8,20 +8,24 @@
 //      the extras stream were requested during the previous batch; varint escapes located with
 //      ballot + prefix popcount, single-byte varints read cross-lane from the window, longer ones
 //      by a wave-wide scan of 3-state transition maps (the prefix varint is a 3-state automaton);
-//      output / literal cursors by DPP prefix sums;
-//   2. requests the literals, runs the dependency analysis while they fly, requests the sources
-//      that are older than the ring, then puts literals and matches sequence-per-lane into an LDS
-//      ring that holds the last RING_BYTES (4 KiB) of output (the sliding window): straight-line
-//      exact-length register puts (aligned LDS accesses + v_alignbyte; unaligned DS accesses are
-//      8x slower on gfx950);
+//      output / literal cursors by DPP prefix sums; all bounds checks branch-free;
+//   2. keeps the last RING_BYTES (4 KiB) of output — the sliding window — in an LDS ring whose
+//      not-yet-written part is kept ZERO. A literal run or a match of any alignment is then put
+//      as whole dwords: the bytes are shifted onto the destination's dword grid once, masked to
+//      the run, and OR-ed in with ds_or_b32 (two neighbouring runs meet in one dword without a
+//      read-modify-write in registers and without byte stores). Literals arrive from memory already
+//      on the destination grid (the load address is biased by the destination's byte phase),
+//      ring sources need one v_alignbyte per dword, sources older than the ring come back from
+//      the block's own output through L2 with the same biased unaligned load;
 //   3. orders matches that depend on other matches of the same batch with exact dependency masks
-//      checked against a ballot of finished lanes (no barrier); the last few dependent ones are
-//      finished one by one, in stream order, by the whole wave;
+//      checked against a ballot of finished lanes (no barrier); simple containments are redirected
+//      to the earlier match's own source; the last few dependent ones are finished one by one, in
+//      stream order, by the whole wave;
 //   4. long copies are done by the whole wave, 16 B per lane; overlapping matches (offset <
 //      length) become a series of non-overlapping copies whose distance doubles (a period stays
 //      a period), so runs need no byte loop;
 //   5. streams finished 16-byte chunks from the ring to HBM, one coalesced
-//      global_store_dwordx4 per lane.
+//      global_store_dwordx4 per lane, and zeroes the part of the ring the next batch will fill.
 // RLE and PivCo (Huffman) literal / token sections are expanded first into a scratch slot
 // (rle_expand below, zxc_pivco.inc); checksums by zxc_rapidhash.inc; a dictionary prefix is a
 // template variant. Launch order: heaviest blocks first (zxc_order_* kernels at the end).
@@ -33,13 +37,15 @@
 
 typedef unsigned __int128 u128;
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef v4u __attribute__((aligned(1))) v4u_unaligned;
+
+#include "zxc_lds.h"
 
 #ifndef RING_BYTES
-#define RING_BYTES 4096u   // sliding window kept in LDS; older history is read back through L2 (A/B: 2/4/8/16 KiB, 4 wins on the silesia mix)
+#define RING_BYTES 4096u   // sliding window kept in LDS; older history is read back through L2
 #endif
 #define RING_MASK (RING_BYTES - 1u)
 #define RING_WORDS (RING_BYTES / 4u)
-#define RING_WMASK (RING_WORDS - 1u)
 #ifndef REDIRECT_PASSES
 #define REDIRECT_PASSES 2   // chained containment levels resolved before round 0 (A/B: 0: -6 %, 1: -2 %, 2: best, 3: -1 %)
 #endif
@@ -47,14 +53,17 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 #define SPARSE_MAX 8   // at most this many unfinished sequences after a round: finish them one by one
 #endif
 #ifndef TILE_MAX
-// A batch never spans more output than this. Anything up to RING_BYTES - 16 is correct (the ring must hold the
-// batch plus the not yet flushed tail of the previous one); a larger tile keeps all 64 lanes busy on highly
-// compressible data (long matches) at the price of a shorter window behind the batch (more far reads).
-// A/B on the silesia mix: 1536: -4 %, 2048: 0, 3072..4032: +2 % (+12 % on the ratio-8.8 class).
+// A batch never spans more output than this: the ring must hold the batch, the not yet flushed tail of the
+// previous one (< 16 B) and the round-up of the zeroed region to 16 B.
 #define TILE_MAX 3584u
 #endif
-#define SHORT_MAX 32u    // one register step of a lane-per-sequence copy
-#define MED_MAX 128u     // matches up to this long are copied lane-per-sequence (4 steps)
+#ifndef LIT_MED
+#define LIT_MED 48u      // literal runs up to this long are put lane-per-sequence (16-byte grid steps), longer ones by the whole wave
+#endif
+#ifndef MATCH_MED
+#define MATCH_MED 128u   // matches up to this long are copied lane-per-sequence (16-byte grid steps)
+#endif
+#define BYTEWISE_MAX 32u // short-period overlapping matches up to this long: lane-local byte loop
 
 // zxc_error_t values (reference include/zxc_error.h:38-74)
 #define E_DST_TOO_SMALL (-2)
@@ -67,19 +76,10 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 #define E_BAD_BLOCK_TYPE (-13)
 #define E_DICT_REQUIRED (-15)
 
-// timing-ablation switches (debug entry point only; decoded bytes are wrong when set)
-#define DBG_NO_LIT 1u
-#define DBG_NO_FAR 2u
-#define DBG_NO_MATCH 4u
-#define DBG_NO_STORE 8u
-#define DBG_NO_LONG 16u
-#define DBG_NO_DEPS 32u
-#define DBG_NO_SHORT 64u
+// timing-ablation switches of the PivCo decoder (experiment builds only; see ZXC_EXPERIMENT below)
 #define DBG_NO_SEQ 512u      // stop after the literal / token sections are expanded (timing only)
 #define DBG_PIV_NO_P2 1024u  // PivCo: skip the bottom-up merges (timing only)
 #define DBG_PIV_NO_P1 2048u  // PivCo: skip everything after the tree set-up (timing only)
-#define DBG_FAR_L2 256u   // far reads all hit one small region (timing only: cost without the HBM round trip)
-#define DBG_LIT_L1 128u   // literal gathers read a fixed coalesced L1-resident address (timing only)
 
 #ifdef EXP_PHASES  // experiment only: per-phase shader-clock totals of each block, written over the block's first 32 output bytes
 #define PH(i) do { const uint64_t t_ = __builtin_readcyclecounter(); ph[i] += (uint32_t)(t_ - ph_last); ph_last = t_; } while (0)
@@ -88,10 +88,10 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 #endif
 
 struct __attribute__((aligned(16))) WaveLds {
-    uint32_t ring[RING_WORDS];          // last 16 KiB of output, position p at byte p & RING_MASK
+    uint32_t ring[RING_WORDS];          // last RING_BYTES of output, position p at byte p & RING_MASK; bytes not yet written are zero
+    uint32_t tmask[17 * 4];             // tmask[4 t + j]: byte mask of dword j of a 16-byte group that keeps the group's first t bytes
     uint32_t vval[128];                 // values of the batch's varints, in stream order
     uint32_t vpos[130];                 // their byte positions in the extras stream (+ end cursor)
-    uint32_t trash[64];                 // per-lane sink for predicated-off stores (cheaper than exec juggling)
 };
 
 // ---------------------------------------------------------------- small helpers
@@ -137,14 +137,16 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // ------------------------------------------------------------------ ring access
 __device__ __forceinline__ uint8_t* ring8(WaveLds& L) { return (uint8_t*)L.ring; }
-__device__ __forceinline__ uint32_t ring_rd8(WaveLds& L, uint32_t pos) { return ring8(L)[pos & RING_MASK]; }
-__device__ __forceinline__ void ring_wr8(WaveLds& L, uint32_t pos, uint32_t v) { ring8(L)[pos & RING_MASK] = (uint8_t)v; }
+__device__ __forceinline__ uint32_t ring_rd8(WaveLds& L, uint32_t pos) { return LDS_LD8(ring8(L) + (pos & RING_MASK)); }
+__device__ __forceinline__ void ring_wr8(WaveLds& L, uint32_t pos, uint32_t v) { LDS_ST8(ring8(L) + (pos & RING_MASK), v); }
+__device__ __forceinline__ uint32_t ring_rd32(WaveLds& L, uint32_t pos4) { return LDS_LD32(ring8(L) + (pos4 & RING_MASK)); }
+__device__ __forceinline__ void ring_or32(WaveLds& L, uint32_t pos4, uint32_t v) { LDS_OR32(ring8(L) + (pos4 & RING_MASK), v); }
 // 16 bytes starting at any position: aligned dword reads + v_alignbyte
 __device__ __forceinline__ v4u ring_rd128(WaveLds& L, uint32_t pos) {
-    const uint32_t i = (pos & RING_MASK) >> 2;
+    const uint32_t b = pos & ~3u;
     const uint32_t sh = pos & 3u;
-    const uint32_t w0 = L.ring[i], w1 = L.ring[(i + 1u) & RING_WMASK], w2 = L.ring[(i + 2u) & RING_WMASK],
-                   w3 = L.ring[(i + 3u) & RING_WMASK], w4 = L.ring[(i + 4u) & RING_WMASK];
+    const uint32_t w0 = ring_rd32(L, b), w1 = ring_rd32(L, b + 4u), w2 = ring_rd32(L, b + 8u), w3 = ring_rd32(L, b + 12u),
+                   w4 = ring_rd32(L, b + 16u);
     v4u r;
     r.x = __builtin_amdgcn_alignbyte(w1, w0, sh);
     r.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
@@ -152,53 +154,22 @@ __device__ __forceinline__ v4u ring_rd128(WaveLds& L, uint32_t pos) {
     r.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
     return r;
 }
-__device__ __forceinline__ v4u ring_rd128_aligned(WaveLds& L, uint32_t pos16) {
-    return *(const v4u*)(L.ring + ((pos16 & RING_MASK) >> 2));
-}
-__device__ __forceinline__ void ring_wr128_aligned(WaveLds& L, uint32_t pos16, v4u v) {
-    *(v4u*)(L.ring + ((pos16 & RING_MASK) >> 2)) = v;
-}
+__device__ __forceinline__ v4u ring_rd128_aligned(WaveLds& L, uint32_t pos16) { return LDS_LD128(ring8(L) + (pos16 & RING_MASK)); }
+__device__ __forceinline__ void ring_wr128_aligned(WaveLds& L, uint32_t pos16, v4u v) { LDS_ST128(ring8(L) + (pos16 & RING_MASK), v); }
 
-// Exact-length store of n (<= 4*NW) bytes held in registers s[0..NW) (byte k of the run =
-// byte k of the register array) at output position d, any alignment, no loops:
-// the registers are funnel-shifted onto the destination's dword grid (v_alignbyte with a
-// per-lane shift), whole dwords go out as ds_write_b32, the <= 3 head bytes and <= 3 tail
-// bytes as ds_write_b8. `tailw` must hold the 4 source bytes starting at put_tail_index().
-__device__ __forceinline__ uint32_t put_tail_index(uint32_t d, uint32_t n) {
-    const uint32_t a = d & 3u;
-    uint32_t hl = a ? 4u - a : 0u;
-    if (hl > n) hl = n;
-    return hl + ((n - hl) & ~3u);
+// A group = 4 dwords of the destination's dword grid (16 bytes at a 4-aligned position).
+// Keeps the first t (0..16) bytes of a group.
+__device__ __forceinline__ v4u group_keep_first(WaveLds& L, const v4u d, uint32_t t) {
+    const v4u m = LDS_LD128((const uint8_t*)L.tmask + 16u * t);
+    return d & m;
 }
-template <int NW>
-__device__ __forceinline__ void ring_put(WaveLds& L, uint32_t d, uint32_t n, const uint32_t (&s)[NW], uint32_t tailw,
-                                         bool act) {
-    const uint32_t a = d & 3u;
-    uint32_t hl = a ? 4u - a : 0u;
-    if (hl > n) hl = n;
-    if (!act) { hl = 0; n = 0; }
-    const uint32_t rem = n - hl;
-    const uint32_t ts = hl + (rem & ~3u);
-    const uint32_t tl = rem & 3u;
-    const uint32_t sh = (4u - a) & 3u;
-    const uint32_t e = act ? a + n : 0u;  // end of the run on the destination dword grid
-    uint8_t* const l8 = (uint8_t*)&L;     // ring bytes first, then the other members
-    const uint32_t trash8 = (uint32_t)__builtin_offsetof(WaveLds, trash) + 4u * (uint32_t)(threadIdx.x & 63u);
-    // Stores are unconditional: a lane with nothing to store at a slot aims at its private trash
-    // dword instead (one v_cndmask on the address; no exec save/restore per store).
-#pragma unroll
-    for (int b = 0; b < 3; b++)  // head bytes (only when d is not dword aligned)
-        l8[((uint32_t)b < hl) ? ((d + b) & RING_MASK) : trash8] = (uint8_t)(s[0] >> (8 * b));
-#pragma unroll
-    for (int j = 0; j < NW; j++) {  // destination dword j covers grid bytes [4j, 4j+4)
-        const uint32_t hi = s[j], lo = j > 0 ? s[j - 1] : 0u;
-        const uint32_t t = a ? __builtin_amdgcn_alignbyte(hi, lo, sh) : hi;
-        const bool w = 4u * j >= a && 4u * j + 4u <= e;
-        *(uint32_t*)(l8 + (w ? ((d - a + 4u * j) & RING_MASK) : trash8)) = t;
-    }
-#pragma unroll
-    for (int b = 0; b < 3; b++)  // tail bytes
-        l8[((uint32_t)b < tl) ? ((d + ts + b) & RING_MASK) : trash8] = (uint8_t)(tailw >> (8 * b));
+// Byte mask that clears the first a (0..3) bytes of a dword: bytes [3-a, 7-a) of 00 00 00 FF FF FF FF FF.
+__device__ __forceinline__ uint32_t head_mask(uint32_t a) { return __builtin_amdgcn_alignbyte(0xFFFFFFFFu, 0xFF000000u, 3u - a); }
+__device__ __forceinline__ void ring_or_group(WaveLds& L, uint32_t gpos4, const v4u d) {
+    ring_or32(L, gpos4, d.x);
+    ring_or32(L, gpos4 + 4u, d.y);
+    ring_or32(L, gpos4 + 8u, d.z);
+    ring_or32(L, gpos4 + 12u, d.w);
 }
 
 // Per-block view shared by the copy routines.
@@ -207,61 +178,20 @@ struct Out {
     uint32_t out_len;    // bytes of it the caller keeps
     uint32_t out_pad;    // out_len rounded up to 16 (readable/writable)
     uint32_t flushed;    // output positions below this are in global memory (multiple of 16)
-    uint32_t dbg;
     const uint8_t* dict; // dictionary prefix: logically occupies output positions [-dict_size, 0)
     uint32_t dict_size;
 };
 
 // Already-final output at position q that has left the ring: read it back from the
 // block's own output (nt: served by L2, where the write-through stores already are).
+// Global loads take any byte alignment, so the 16 bytes come back in place.
 __device__ __forceinline__ v4u far_rd128(const Out& O, uint32_t q) {
     v4u z = {0, 0, 0, 0};
-    if ((O.dbg & DBG_NO_FAR) || q + 20u > O.out_pad) return z;  // 2nd case: only a malformed, oversize block
-    if (O.dbg & DBG_FAR_L2) q &= 1023u;
-    const uint8_t* a = O.dst + (q & ~3u);
-    const v4u g = __builtin_nontemporal_load((const v4u*)a);
-    const uint32_t g4 = __builtin_nontemporal_load((const uint32_t*)(a + 16));
-    const uint32_t sh = q & 3u;
-    v4u r;
-    r.x = __builtin_amdgcn_alignbyte(g.y, g.x, sh);
-    r.y = __builtin_amdgcn_alignbyte(g.z, g.y, sh);
-    r.z = __builtin_amdgcn_alignbyte(g.w, g.z, sh);
-    r.w = __builtin_amdgcn_alignbyte(g4, g.w, sh);
-    return r;
-}
-// The same in two halves, so that the loads can be requested long before their bytes are needed:
-// far_issue() only starts the (dword-aligned) loads, far_take() shifts them into place.
-struct FarRaw { v4u a, b; uint32_t c; };
-__device__ __forceinline__ FarRaw far_issue(const Out& O, uint32_t q, bool second) {
-    FarRaw r;
-    r.a = (v4u){0, 0, 0, 0};
-    r.b = (v4u){0, 0, 0, 0};
-    r.c = 0;
-    if ((O.dbg & DBG_NO_FAR) || q + 36u > O.out_pad) return r;
-    if (O.dbg & DBG_FAR_L2) q &= 1023u;
-    const uint8_t* p = O.dst + (q & ~3u);
-    r.a = __builtin_nontemporal_load((const v4u*)p);
-    if (second) {
-        r.b = __builtin_nontemporal_load((const v4u*)(p + 16));
-        r.c = __builtin_nontemporal_load((const uint32_t*)(p + 32));
-    } else {
-        r.b.x = __builtin_nontemporal_load((const uint32_t*)(p + 16));
-    }
-    return r;
-}
-__device__ __forceinline__ void far_take(const FarRaw& r, uint32_t q, v4u& lo16, v4u& hi16) {
-    const uint32_t sh = q & 3u;
-    lo16.x = __builtin_amdgcn_alignbyte(r.a.y, r.a.x, sh);
-    lo16.y = __builtin_amdgcn_alignbyte(r.a.z, r.a.y, sh);
-    lo16.z = __builtin_amdgcn_alignbyte(r.a.w, r.a.z, sh);
-    lo16.w = __builtin_amdgcn_alignbyte(r.b.x, r.a.w, sh);
-    hi16.x = __builtin_amdgcn_alignbyte(r.b.y, r.b.x, sh);
-    hi16.y = __builtin_amdgcn_alignbyte(r.b.z, r.b.y, sh);
-    hi16.z = __builtin_amdgcn_alignbyte(r.b.w, r.b.z, sh);
-    hi16.w = __builtin_amdgcn_alignbyte(r.c, r.b.w, sh);
+    if (q + 16u > O.out_pad) return z;  // only a malformed, oversize block
+    return __builtin_nontemporal_load((const v4u_unaligned*)(O.dst + q));
 }
 __device__ __forceinline__ uint32_t far_rd8(const Out& O, uint32_t q) {
-    if ((O.dbg & DBG_NO_FAR) || q >= O.out_pad) return 0;
+    if (q >= O.out_pad) return 0;
     return __builtin_nontemporal_load(O.dst + q);
 }
 
@@ -279,7 +209,6 @@ __device__ __forceinline__ void flush_to(WaveLds& L, Out& O, uint32_t upto, int 
     const uint32_t end = upto & ~15u;
     for (uint32_t c = O.flushed + 16u * (uint32_t)lane; c < end; c += 1024u) {
         const v4u v = ring_rd128_aligned(L, c);
-        if (O.dbg & DBG_NO_STORE) continue;
         if (c + 16u <= O.out_len) {
             *(v4u*)(O.dst + c) = v;  // one coalesced 16 B store per lane
         } else if (c < O.out_len) {
@@ -290,9 +219,17 @@ __device__ __forceinline__ void flush_to(WaveLds& L, Out& O, uint32_t upto, int 
     if (end > O.flushed) O.flushed = end;
 }
 
+// Zero the ring for output positions [from16, to16) (both multiples of 16, at most RING_BYTES apart):
+// the part of the window the coming batch fills with ds_or puts.
+__device__ __forceinline__ void ring_zero(WaveLds& L, uint32_t from16, uint32_t to16, int lane) {
+    const v4u z = {0, 0, 0, 0};
+    for (uint32_t c = from16 + 16u * (uint32_t)lane; c < to16; c += 1024u) ring_wr128_aligned(L, c, z);
+}
+
 // Whole-wave copy of n bytes to output position dpos. The source is either output
 // position spos (ring when >= ring_lo, L2 otherwise; must not overlap the
 // destination: n <= dpos - spos) or, when lit != nullptr, the literal stream.
+// Plain (not OR) stores: every destination byte is written exactly once, whatever was there.
 template <bool DICT>
 __device__ void coop_copy(WaveLds& L, const Out& O, uint32_t dpos, uint32_t spos, const uint8_t* lit, uint32_t n,
                           uint32_t ring_lo, int lane) {
@@ -448,7 +385,7 @@ __device__ __forceinline__ uint32_t parse_varints(const uint8_t* ext, uint32_t e
 
 // ------------------------------------------------------------------ block decode
 struct LzStreams {
-    const uint8_t* lit;   // literal bytes (payload, or expanded scratch)
+    const uint8_t* lit;   // literal bytes (payload, or expanded scratch); 3 bytes before and 16 after are readable
     uint32_t n_lit;
     const uint8_t* tok;   // GLO: 1 B/seq tokens. GHI: 4 B/seq words
     const uint8_t* offs;  // GLO only
@@ -456,8 +393,6 @@ struct LzStreams {
     uint32_t ext_size;
     uint32_t n_seq;
     uint32_t off8;        // GLO 1-byte offsets
-    uint32_t ghi;
-    uint32_t dbg;         // ablation switches
     const uint8_t* dict;  // dictionary prefix (or nullptr)
     uint32_t dict_size;
 };
@@ -475,11 +410,12 @@ __device__ __forceinline__ uint32_t lanes_le(uint32_t sorted, uint32_t x) {
 }
 
 // Token and offset of sequence s, undecoded (GHI: the 32-bit word; GLO: token byte, offset - 1).
+template <bool GHI>
 __device__ __forceinline__ void load_seq_raw(const LzStreams& S, uint32_t s, uint32_t& raw_t, uint32_t& raw_o) {
     raw_t = 0;
     raw_o = 0;
     if (s < S.n_seq) {
-        if (S.ghi) raw_t = ld32(S.tok + 4ull * s);
+        if (GHI) raw_t = ld32(S.tok + 4ull * s);
         else {
             raw_t = ld8(S.tok + s);
             raw_o = S.off8 ? ld8(S.offs + s) : ld16(S.offs + 2ull * s);
@@ -488,27 +424,41 @@ __device__ __forceinline__ void load_seq_raw(const LzStreams& S, uint32_t s, uin
 }
 
 // Executes all sequences of one block. Returns decoded size or a negative error.
-template <bool DICT>
+//
+// The ring invariant that makes the ds_or puts work: at the top of every batch all ring bytes of
+// output positions [p, z_end) are zero (p = bytes produced so far, z_end a multiple of 16), and
+// before a batch is executed the zeroed region is extended to cover the batch ([z_end, z_new),
+// stale window data one lap old that nothing can reference any more: ring_lo = z_new - RING_BYTES).
+template <bool DICT, bool GHI>
 __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __restrict__ dst, uint32_t out_len, uint32_t cap,
                              WaveLds& L, int lane) {
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const uint32_t n_total = S.n_seq + 1u;  // + pseudo sequence carrying the trailing literals
+    const uint32_t n_lit = S.n_lit;
     Out O;
     O.dst = dst;
     O.out_len = out_len;
     O.out_pad = (out_len + 15u) & ~15u;
     O.flushed = 0;
-    O.dbg = S.dbg;
     O.dict = S.dict;
     O.dict_size = S.dict_size;
     uint32_t p = 0, lp = 0, cur = 0, dead = 0, seq_base = 0;
+    uint32_t z_end = RING_BYTES;
 #ifdef EXP_PHASES
     uint32_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t ph_last = __builtin_readcyclecounter();
 #endif
 
+    // tail-mask table + an all-zero ring
+    for (uint32_t i = (uint32_t)lane; i < 68u; i += 64u) {
+        const int v = (int)(i >> 2) - 4 * (int)(i & 3u);  // bytes of dword (i & 3) kept when the first (i >> 2) bytes of the group are
+        LDS_ST32((uint8_t*)L.tmask + 4u * i, v <= 0 ? 0u : (v >= 4 ? 0xFFFFFFFFu : ((1u << (8 * v)) - 1u)));
+    }
+    ring_zero(L, 0u, RING_BYTES, lane);
+    wave_lds_fence();
+
     uint32_t raw_t, raw_o;
-    load_seq_raw(S, (uint32_t)lane, raw_t, raw_o);
+    load_seq_raw<GHI>(S, (uint32_t)lane, raw_t, raw_o);
     uint32_t xw0 = (uint32_t)lane < S.ext_size ? ld8(S.ext + lane) : 0u;
     uint32_t xw1 = 64u + (uint32_t)lane < S.ext_size ? ld8(S.ext + 64u + lane) : 0u;
 
@@ -516,22 +466,21 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
         const uint32_t s = seq_base + (uint32_t)lane;
         const bool real = s < S.n_seq;
         const bool valid = s < n_total;
-        uint32_t ll = 0, ml = 0, off = 1;
-        bool escL = false, escM = false;
-        if (real) {  // (raw_t / raw_o were requested while the previous batch was being copied)
-            if (S.ghi) {
-                ll = raw_t >> 24;
-                ml = (raw_t >> 16) & 255u;
-                off = (raw_t & 0xFFFFu) + 1u;
-                escL = ll == 255u;
-                escM = ml == 255u;
-            } else {
-                ll = raw_t >> 4;
-                ml = raw_t & 15u;
-                off = 1u + raw_o;
-                escL = ll == 15u;
-                escM = ml == 15u;
-            }
+        // (raw_t / raw_o were requested while the previous batch was being copied; they are 0 beyond n_seq)
+        uint32_t ll, ml, off;
+        bool escL, escM;
+        if (GHI) {
+            ll = raw_t >> 24;
+            ml = (raw_t >> 16) & 255u;
+            off = (raw_t & 0xFFFFu) + 1u;
+            escL = real & (ll == 255u);
+            escM = real & (ml == 255u);
+        } else {
+            ll = raw_t >> 4;
+            ml = raw_t & 15u;
+            off = 1u + raw_o;
+            escL = real & (ll == 15u);
+            escM = real & (ml == 15u);
         }
         const uint64_t mL = __ballot(escL), mM = __ballot(escM);
         const uint32_t nv = __popcll(mL) + __popcll(mM);
@@ -563,7 +512,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                 if (escM && r2 < kbad) ml += L.vval[r2];
             }
         }
-        if (real) ml += 5u;
+        ml += real ? 5u : 0u;
 
         // cursors: inclusive scans of (ll+ml) and ll
         uint32_t len = ll + ml;
@@ -571,14 +520,17 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
         const uint32_t Lincl0 = wave_scan_add(ll, lane);
         const uint32_t est = p + (Eincl0 - len);  // where this sequence's literals land
         const uint32_t lst = lp + (Lincl0 - ll);  // its first literal
+        // bounds (reference: OVERFLOW src/lib/zxc_decompress.c:1184, BAD_OFFSET :1190), all lanes, no branches
+        const bool pseudo = valid & !real;  // whatever literals are left
+        const bool lit_over = lst > n_lit;
+        const uint32_t lit_left = n_lit - lst;
+        const bool ovf_real = (est > cap) | (len > cap - est) | lit_over | (ll > lit_left);
+        const bool ovf_pseudo = (est > cap) | lit_over | (lit_left > cap - est);
+        const bool bad_off = off > est + ll + (DICT ? S.dict_size : 0u);
         int err = 0;
-        if (real) {
-            if (est > cap || len > cap - est || lst > S.n_lit || ll > S.n_lit - lst) err = E_OVERFLOW;
-            else if (off > est + ll + (DICT ? S.dict_size : 0u)) err = E_BAD_OFFSET;
-        } else if (valid) {  // pseudo sequence: whatever literals are left
-            if (est > cap || lst > S.n_lit || S.n_lit - lst > cap - est) err = E_OVERFLOW;
-            else { ll = S.n_lit - lst; len = ll; }
-        }
+        err = (real & bad_off) ? E_BAD_OFFSET : err;
+        err = ((real & ovf_real) | (pseudo & ovf_pseudo)) ? E_OVERFLOW : err;
+        if (pseudo & !ovf_pseudo) { ll = lit_left; len = lit_left; }
         const uint32_t M = est + ll;
         const uint32_t E = est + len;
 
@@ -594,7 +546,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
 
         // the next batch starts at sequence seq_base + max(k, 1): request its tokens and offsets now
         uint32_t nraw_t, nraw_o;
-        load_seq_raw(S, seq_base + (k ? k : 1u) + (uint32_t)lane, nraw_t, nraw_o);
+        load_seq_raw<GHI>(S, seq_base + (k ? k : 1u) + (uint32_t)lane, nraw_t, nraw_o);
         // extras cursor after the k sequences consumed (the rest is re-parsed next turn), and its window
         if (parsed) {
             const uint32_t kk = k ? k : 1u;
@@ -608,7 +560,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
         const uint32_t nxw1 = cur + 64u + (uint32_t)lane < S.ext_size ? ld8(S.ext + cur + 64u + lane) : 0u;
         PH(0);
         if (k == 0u) {
-            // ---- one giant sequence (> TILE_MAX bytes): the whole wave walks it in pieces
+            // ---- one giant sequence (> TILE_MAX bytes): the whole wave walks it in pieces (plain stores)
             const uint32_t gll = uni(ll), gml = uni(ml), goff = uni(off);
             uint32_t donel = 0;
             while (donel < gll) {
@@ -624,33 +576,35 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             p += gll + gml;
             lp += gll;
             k = 1;
+            // restore the ring invariant: zero from p to the end of its 16-byte chunk; beyond that
+            // the next batch zeroes what it needs
+            z_end = (p + 15u) & ~15u;
+            if (p + (uint32_t)lane < z_end) ring_wr8(L, p + (uint32_t)lane, 0u);
             PH(7);
         } else {
             const bool mine = (uint32_t)lane < k;
             const uint32_t tile_end = __shfl(E, (int)(k - 1u));
-            const uint32_t ring_lo = tile_end > RING_BYTES ? tile_end - RING_BYTES : 0u;
+            const uint32_t z_new = (tile_end + 15u) & ~15u;
+            const uint32_t ring_lo = z_new > RING_BYTES ? z_new - RING_BYTES : 0u;
+            if (z_new > z_end) {
+                ring_zero(L, z_end, z_new, lane);
+                z_end = z_new;
+            }
 
-            // ---- literals, part 1: request the first 48 literal bytes of every sequence now; the loads fly
-            // while the dependency analysis below (registers and cross-lane traffic only) runs.
-            const bool lshort = mine && ll != 0u && ll <= 64u && !(S.dbg & DBG_NO_LIT);
-            const bool lact1 = lshort && ll > 16u;
-            const uint32_t ln0 = ll < 16u ? ll : 16u, ln1 = (ll - 16u < 16u) ? ll - 16u : 16u;
-            const bool lact2 = lshort && ll > 32u;  // (3/4 of the batches have such a sequence: worth a request up front)
-            const uint32_t ln2 = (ll - 32u < 16u) ? ll - 32u : 16u;
+            // ---- literals, part 1. A run lands on its destination's dword grid: group g of the run is the
+            // 16 bytes at output position (est & ~3) + 16 g, and they come from literal offset
+            // lst - (est & 3) + 16 g — memory loads take any alignment, so no shift is needed at all.
+            // The first three groups are requested now; the loads fly while the dependency analysis
+            // below (registers and cross-lane traffic only) runs.
+            const uint32_t la = est & 3u;
+            const uint32_t le = la + ll;              // end of the run on its grid (bytes from the grid origin)
+            const bool lshort = mine && ll != 0u && ll <= LIT_MED;
+            const uint8_t* lsrc = S.lit + (int32_t)(lst - la);
             v4u lv0 = {0, 0, 0, 0}, lv1 = {0, 0, 0, 0}, lv2 = {0, 0, 0, 0};
-            uint32_t lt0 = 0, lt1 = 0, lt2 = 0;
             if (lshort) {
-                const uint8_t* lsrc = (S.dbg & DBG_LIT_L1) ? S.lit + 16u * (uint32_t)lane : S.lit + lst;
                 lv0 = ld128(lsrc);
-                lt0 = ld32(lsrc + put_tail_index(est, ln0));
-                if (lact1) {
-                    lv1 = ld128(lsrc + 16u);
-                    lt1 = ld32(lsrc + 16u + put_tail_index(est + 16u, ln1));
-                }
-                if (lact2) {
-                    lv2 = ld128(lsrc + 32u);
-                    lt2 = ld32(lsrc + 32u + put_tail_index(est + 32u, ln2));
-                }
+                if (le > 16u) lv1 = ld128(lsrc + 16u);
+                if (le > 32u) lv2 = ld128(lsrc + 32u);
             }
 
             // ---- matches. Sequence i may only copy once every earlier match of this batch
@@ -660,19 +614,19 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             const uint32_t qa = M - off;    // (wraps negative then; only src_rd8 / coop paths read it)
             const uint32_t qb = fromdict ? ((off - M < ml) ? ((ml - (off - M) < M) ? ml - (off - M) : M) : 0u)
                                          : ((qa + ml < M) ? qa + ml : M);
-            bool pending = mine && ml != 0u && !(S.dbg & DBG_NO_MATCH);
+            bool pending = mine && ml != 0u;
             uint64_t need = 0;
             uint32_t qsrc = qa;  // where the copy reads from (qa unless redirected)
             {
                 // all lanes run the same bpermute sequence; only lanes reaching into the batch use it
                 const uint32_t ja = lanes_le(Es, fromdict ? 0u : qa);     // first lane with E > qa
                 const uint32_t jbp = lanes_le(Ms, qb ? qb - 1u : 0u);    // number of lanes with M < qb
-                if (pending && qb > p && jbp > ja && !(S.dbg & DBG_NO_DEPS))
+                if (pending && qb > p && jbp > ja)
                     need = ((jbp >= 64u) ? ~0ull : ((1ull << jbp) - 1ull)) & ~((1ull << ja) - 1ull);
                 // Redirect: when my whole source sits inside ONE earlier match j of this batch (within
                 // its first period) and j has no pending dependency itself, my bytes equal j's source
-                // bytes at the same displacement: read those instead and drop the dependency. Three
-                // passes collapse chains of such containments (each pass resolves one more level).
+                // bytes at the same displacement: read those instead and drop the dependency. Each
+                // pass collapses one more level of such containments.
                 const int jl = (int)(ja & 63u);
                 const uint32_t jM = __shfl(M, jl), jE = __shfl(E, jl), jo = __shfl(off, jl);
                 const bool simple = need != 0ull && !fromdict && jbp == ja + 1u && off >= ml && qa >= jM && qb <= jE && qb - jM <= jo;
@@ -687,61 +641,63 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                     }
                 }
             }
+            // A match lands on ITS destination's dword grid the same way: group g = 16 bytes at
+            // (M & ~3) + 16 g, from source position qsrc - (M & 3) + 16 g.
+            const uint32_t ma = M & 3u;
+            const uint32_t me = ma + ml;
+            const uint32_t mg = M - ma;          // grid origin (4-aligned output position)
+            const uint32_t sg = qsrc - ma;       // its source (may be "negative" by up to 3 for qsrc < 3: only masked-off bytes)
             const bool overlap = off < ml;
-            // lane-per-sequence in 32-byte steps works whenever a step's source is complete before
-            // the step runs: no overlap at all, or a period of at least one step.
-            const bool stepable = !fromdict && ml <= MED_MAX && (!overlap || off >= SHORT_MAX);
-            const bool bytewise = !fromdict && overlap && off < SHORT_MAX && ml <= SHORT_MAX;
+            // lane-per-sequence in 16-byte groups works whenever a group's source is complete before
+            // the group is put: no overlap at all, or a period of at least one group (+ grid phase).
+            const bool farsrc = qsrc < ring_lo;
+            const bool stepable = !fromdict && ml <= MATCH_MED && (!overlap || off >= 16u) && !(farsrc && qsrc < 4u);
+            const bool bytewise = !fromdict && overlap && off < 16u && ml <= BYTEWISE_MAX && !farsrc;
             const bool is_long = !stepable && !bytewise;
             bool far_waited = false;
             // Sources older than the ring come back from the block's own output through L2 (~700 clk). Such a
-            // lane depends on nothing in this batch, so its first 32 bytes are requested here: the literal
+            // lane depends on nothing in this batch, so its first two groups are requested here: the literal
             // loads above are older (VMEM returns in order), so waiting for them below does not wait for
             // these, and the literal puts run under the round trip.
-            const bool pf = pending && need == 0ull && stepable && qsrc < ring_lo && qsrc + 36u <= O.out_pad &&
-                            !(S.dbg & DBG_NO_SHORT);
-            FarRaw fr;
-            fr.a = (v4u){0, 0, 0, 0};
-            fr.b = (v4u){0, 0, 0, 0};
-            fr.c = 0;
+            const bool pf = pending && need == 0ull && stepable && farsrc && sg + 32u <= O.out_pad;
+            v4u fr0 = {0, 0, 0, 0}, fr1 = {0, 0, 0, 0};
             // (unconditional wait: the literal data is needed next anyway, and with every older access known to
             // be complete on both paths the compiler does not force these loads to finish before the literal puts)
             __builtin_amdgcn_s_waitcnt(0);  // also: the flush stores that wrote those bytes have landed
             far_waited = true;
-            if (pf) fr = far_issue(O, qsrc, ml > 16u);
+            if (pf) {
+                fr0 = __builtin_nontemporal_load((const v4u_unaligned*)(O.dst + sg));
+                if (me > 16u) fr1 = __builtin_nontemporal_load((const v4u_unaligned*)(O.dst + sg + 16u));
+            }
             PH(2);
-            // ---- literals, part 2: lane-per-sequence exact-length puts, 16 B per step (up to 64 B); longer
-            // runs are copied by the whole wave
+            // ---- literals, part 2: one masked ds_or group per 16 bytes of grid
             {
+                const uint32_t lg = est - la;
                 {
-                    const uint32_t lw0[4] = {lv0.x, lv0.y, lv0.z, lv0.w};
-                    ring_put<4>(L, est, ln0, lw0, lt0, lshort);
+                    const uint32_t t = lshort ? (le < 16u ? le : 16u) : 0u;
+                    v4u d = group_keep_first(L, lv0, t);
+                    d.x &= head_mask(la);
+                    ring_or_group(L, lg, d);
                 }
-                if (__ballot(lact1)) {
-                    const uint32_t lw1[4] = {lv1.x, lv1.y, lv1.z, lv1.w};
-                    ring_put<4>(L, est + 16u, ln1, lw1, lt1, lact1);
+                if (__ballot(lshort && le > 16u)) {
+                    const uint32_t t = (lshort && le > 16u) ? (le - 16u < 16u ? le - 16u : 16u) : 0u;
+                    ring_or_group(L, lg + 16u, group_keep_first(L, lv1, t));
                 }
-                if (__ballot(lact2)) {
-                    const uint32_t lw2[4] = {lv2.x, lv2.y, lv2.z, lv2.w};
-                    ring_put<4>(L, est + 32u, ln2, lw2, lt2, lact2);
+                if (__ballot(lshort && le > 32u)) {
+                    const uint32_t t = (lshort && le > 32u) ? (le - 32u < 16u ? le - 32u : 16u) : 0u;
+                    ring_or_group(L, lg + 32u, group_keep_first(L, lv2, t));
                 }
 #pragma unroll 1
-                for (uint32_t so = 48u; so < 64u; so += 16u) {
-                    const bool act = lshort && so < ll;
+                for (uint32_t go = 48u; go < LIT_MED + 4u; go += 16u) {
+                    const bool act = lshort && le > go;
                     if (__ballot(act) == 0ull) break;
-                    const uint32_t n = (ll - so < 16u) ? ll - so : 16u;
                     v4u lv = {0, 0, 0, 0};
-                    uint32_t ltail = 0;
-                    if (act) {
-                        const uint8_t* lsrc = (S.dbg & DBG_LIT_L1) ? S.lit + 16u * (uint32_t)lane : S.lit + lst + so;
-                        lv = ld128(lsrc);
-                        ltail = ld32(lsrc + put_tail_index(est + so, n));
-                    }
-                    const uint32_t lw[4] = {lv.x, lv.y, lv.z, lv.w};
-                    ring_put<4>(L, est + so, n, lw, ltail, act);
+                    if (act) lv = ld128(lsrc + go);
+                    const uint32_t t = act ? (le - go < 16u ? le - go : 16u) : 0u;
+                    ring_or_group(L, lg + go, group_keep_first(L, lv, t));
                 }
-                PH(7);  // (experiment builds: slot 7 = literal register steps, slot 1 = long literals)
-                uint64_t lm = __ballot(mine && ll > 64u);
+                PH(7);  // (experiment builds: slot 7 = literal groups, slot 1 = long literals)
+                uint64_t lm = __ballot(mine && ll > LIT_MED);
                 while (lm) {
                     const int j = __ffsll((unsigned long long)lm) - 1;
                     lm &= lm - 1ull;
@@ -756,51 +712,35 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                 if (dm == ~0ull) break;
                 if (round > 70u) return ZXC_DEV_E_INTERNAL;  // cannot happen: the lowest pending lane is always ready
                 const bool can = pending && ((dm & need) == need);
-                // lane-per-sequence copy: 32 source bytes into registers (ring, or L2 when the source
-                // has left the ring), one exact-length put; up to MED_MAX bytes in 4 steps
-                const bool sa = can && stepable && !(S.dbg & DBG_NO_SHORT);
+                // lane-per-sequence copy, one 16-byte grid group per step (up to MATCH_MED bytes)
+                const bool sa = can && stepable;
                 if (__ballot(sa)) {
 #pragma unroll 1
-                    for (uint32_t so = 0; so < MED_MAX; so += SHORT_MAX) {
-                        const bool act = sa && so < ml;
+                    for (uint32_t go = 0; go < MATCH_MED + 4u; go += 16u) {
+                        const bool act = sa && me > go;
                         if (__ballot(act) == 0ull) break;
-                        const uint32_t n = (ml - so < SHORT_MAX) ? ml - so : SHORT_MAX;
-                        const uint32_t q = qsrc + so, d = M + so;
-                        const bool usepf = act && so == 0u && pf;  // requested before the literal puts
-                        const bool isfar = act && q < ring_lo && !usepf;
-                        const uint32_t ts = put_tail_index(d, n);
-                        v4u s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
-                        if (usepf) far_take(fr, q, s0, s1);
+                        const uint32_t q = sg + go;                       // source of this group
+                        const bool usepf = act && pf && go < 32u;         // requested before the literal puts
+                        const bool isfar = act && !usepf && farsrc && q < ring_lo;  // (farsrc lanes have qsrc >= 4: q does not wrap)
+                        v4u d = {0, 0, 0, 0};
+                        if (usepf) d = go == 0u ? fr0 : fr1;
                         if (__ballot(isfar)) {
                             if (!far_waited) { __builtin_amdgcn_s_waitcnt(0); far_waited = true; }
-                            if (isfar) {
-                                s0 = far_rd128(O, q);
-                                if (n > 16u) s1 = far_rd128(O, q + 16u);
-                            }
+                            if (isfar) d = far_rd128(O, q);
                         }
-                        if (act && !isfar && !usepf) {
-                            s0 = ring_rd128(L, q);
-                            if (n > 16u) s1 = ring_rd128(L, q + 16u);
-                        }
-                        uint32_t tw;
-                        {   // the 4 bytes at source index ts, out of the registers just loaded
-                            const uint32_t sw[9] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, 0u};
-                            uint32_t lo = 0, hi = 0;
-#pragma unroll
-                            for (int j = 0; j < 8; j++)
-                                if ((ts >> 2) == (uint32_t)j) { lo = sw[j]; hi = sw[j + 1]; }
-                            tw = __builtin_amdgcn_alignbyte(hi, lo, ts & 3u);
-                        }
-                        const uint32_t sw8[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-                        ring_put<8>(L, d, n, sw8, tw, act);
+                        if (act && !isfar && !usepf) d = ring_rd128(L, q);
+                        const uint32_t t = act ? (me - go < 16u ? me - go : 16u) : 0u;
+                        d = group_keep_first(L, d, t);
+                        if (go == 0u) d.x &= head_mask(ma);
+                        ring_or_group(L, mg + go, d);
                     }
                 }
-                // short period (off < 32 and off < ml <= 32): byte loop over the period [M-off, M)
-                const bool sb = can && bytewise && !(S.dbg & DBG_NO_SHORT);
+                // short period (off < 16, off < ml <= 32): byte loop over the period [M-off, M)
+                const bool sb = can && bytewise;
                 if (__ballot(sb)) {
                     uint32_t r = 0;
 #pragma unroll 1
-                    for (uint32_t t = 0; t < SHORT_MAX; t++) {
+                    for (uint32_t t = 0; t < BYTEWISE_MAX; t++) {
                         const bool act = sb && t < ml;
                         if (__ballot(act) == 0ull) break;
                         if (act) {
@@ -816,7 +756,6 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                     const int j = __ffsll((unsigned long long)lm) - 1;
                     lm &= lm - 1ull;
                     const uint32_t jM = __shfl(M, j), jml = __shfl(ml, j), joff = __shfl(off, j);
-                    if (S.dbg & DBG_NO_LONG) continue;
                     if (jM - joff < ring_lo && !far_waited) { __builtin_amdgcn_s_waitcnt(0); far_waited = true; }
                     coop_match<DICT>(L, O, jM, jml, joff, ring_lo, false, lane);
                 }
@@ -830,7 +769,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                 // every source is complete by construction, and one such copy costs a small fraction of
                 // a full lane-per-sequence round.
                 uint64_t pm = __ballot(pending);
-                if (pm != 0ull && __popcll(pm) <= SPARSE_MAX && !(S.dbg & DBG_NO_DEPS)) {
+                if (pm != 0ull && __popcll(pm) <= SPARSE_MAX) {
                     const uint64_t longm = __ballot(is_long);
                     while (pm) {
                         const int j = __ffsll((unsigned long long)pm) - 1;
@@ -852,6 +791,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                             if (ovl) {
                                 const uint32_t qd = (uint32_t)((float)t * rcp);
                                 r = t - qd * joff;
+                                if ((int32_t)r < 0) r += joff;
                                 if (r >= joff) r -= joff;
                             }
                             if (t < jml) ring_wr8(L, jM + t, ring_rd8(L, jq + r));
@@ -886,7 +826,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
     return (int)p;
 #endif
     // the last chunk may be partial: it only lives in the ring so far
-    if ((p & 15u) != 0u && lane == 0 && !(S.dbg & DBG_NO_STORE)) {
+    if ((p & 15u) != 0u && lane == 0) {
         const uint32_t cs = p & ~15u;
         for (uint32_t kk = 0; cs + kk < p && cs + kk < out_len; kk++) dst[cs + kk] = (uint8_t)ring_rd8(L, cs + kk);
     }
@@ -1019,13 +959,11 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
                                uint32_t dbg, const uint8_t* dict, uint32_t dict_size, const uint8_t* dict_huf) {
     if (comp_sz < 12u) return E_BAD_HEADER;
     LzStreams S;
-    S.dbg = dbg;
     S.dict = dict;
     S.dict_size = dict_size;
     S.n_seq = uni(ld32(data));
     S.n_lit = uni(ld32(data + 4));
     const uint32_t enc_lit = uni(ld8(data + 8)), enc_tok = uni(ld8(data + 9)), enc_off = uni(ld8(data + 11));
-    S.ghi = ghi;
     if (ghi) {
         if (enc_lit != 0u || enc_tok != 0u) return E_CORRUPT;
         const uint32_t avail = comp_sz - 12u;
@@ -1037,7 +975,7 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
         S.off8 = 0;
         S.ext = S.tok + 4ull * S.n_seq;
         S.ext_size = avail - (uint32_t)consumed;
-        return run_sequences<DICT>(S, dst, out_len, cap, L, lane);
+        return run_sequences<DICT, true>(S, dst, out_len, cap, L, lane);
     }
     const uint32_t desc = (enc_lit != 0u ? 4u : 0u) + (enc_tok == 2u ? 4u : 0u);
     if (comp_sz < 12u + desc) return E_BAD_HEADER;
@@ -1055,8 +993,8 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
             if (S.n_lit > cap) return E_DST_TOO_SMALL;
             if (enc_lit == 3u && !dict_huf) return E_DICT_REQUIRED;  // shared table comes with the dictionary
             if (S.n_lit > block_size) return E_CORRUPT;
-            uint8_t* scratch = scratch_acquire(pool, lane);
-            const int rc = pivco_decode(pdata, lit_comp, scratch, S.n_lit, scratch + block_size + 64u,
+            uint8_t* scratch = scratch_acquire(pool, lane) + 16;  // (the executor reads up to 3 bytes below a literal run)
+            const int rc = pivco_decode(pdata, lit_comp, scratch, S.n_lit, scratch + block_size + 48u,
                                   reinterpret_cast<PivLds&>(L), lane, enc_lit == 3u ? dict_huf : nullptr, dbg);
             if (rc != 0) return rc;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1067,7 +1005,7 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
         if (S.n_lit != 0u) {
             if (S.n_lit > cap) return E_DST_TOO_SMALL;
             if (S.n_lit > block_size || lit_comp > avail) return E_CORRUPT;
-            uint8_t* scratch = scratch_acquire(pool, lane);
+            uint8_t* scratch = scratch_acquire(pool, lane) + 16;
             const int rc = rle_expand(pdata, lit_comp, scratch, S.n_lit, lane);
             if (rc != 0) return rc;
             S.lit = scratch;
@@ -1096,8 +1034,10 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
     S.off8 = enc_off;
     S.ext = S.offs + sz_off;
     S.ext_size = avail - (uint32_t)consumed;
+#ifdef ZXC_EXPERIMENT
     if (dbg & DBG_NO_SEQ) return (int)out_len;
-    return run_sequences<DICT>(S, dst, out_len, cap, L, lane);
+#endif
+    return run_sequences<DICT, false>(S, dst, out_len, cap, L, lane);
 }
 
 #ifndef WAVES_PER_SIMD
