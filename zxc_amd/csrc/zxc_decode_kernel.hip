@@ -50,7 +50,7 @@ typedef v4u __attribute__((aligned(1))) v4u_unaligned;
 #define REDIRECT_PASSES 2   // chained containment levels resolved before round 0 (A/B: 0: -6 %, 1: -2 %, 2: best, 3: -1 %)
 #endif
 #ifndef SPARSE_MAX
-#define SPARSE_MAX 8   // at most this many unfinished sequences after a round: finish them one by one
+#define SPARSE_MAX 4   // at most this many unfinished sequences after a round: finish them one by one
 #endif
 #ifndef TILE_MAX
 // A batch never spans more output than this: the ring must hold the batch, the not yet flushed tail of the
@@ -398,6 +398,8 @@ struct LzStreams {
 };
 
 // number of lanes whose (ascending over lanes) value is <= x: binary search by bpermute
+// (A/B on the bench mix: fetching the first three levels' pivots with v_readlane and pairing the two searches'
+// round trips, or counting the last eight lanes with seven independent bpermutes, is within +-1 %)
 __device__ __forceinline__ uint32_t lanes_le(uint32_t sorted, uint32_t x) {
     uint32_t c = 0;
 #pragma unroll
@@ -583,7 +585,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             PH(7);
         } else {
             const bool mine = (uint32_t)lane < k;
-            const uint32_t tile_end = __shfl(E, (int)(k - 1u));
+            const uint32_t tile_end = (uint32_t)__builtin_amdgcn_readlane((int)E, (int)(k - 1u));
             const uint32_t z_new = (tile_end + 15u) & ~15u;
             const uint32_t ring_lo = z_new > RING_BYTES ? z_new - RING_BYTES : 0u;
             if (z_new > z_end) {
@@ -806,7 +808,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                 }
             }
             p = tile_end;
-            lp = __shfl(lst + ll, (int)(k - 1u));
+            lp = (uint32_t)__builtin_amdgcn_readlane((int)(lst + ll), (int)(k - 1u));
             flush_to(L, O, p, lane);
             PH(5);
         }
