@@ -36,6 +36,39 @@ ZXC_EXPORT int64_t zxc_decompress(const void* src, const size_t src_size, void* 
 /* reference include/zxc_buffer.h:195 (impl src/lib/zxc_dispatch.c:1203-1225) */
 ZXC_EXPORT uint64_t zxc_get_decompressed_size(const void* src, const size_t src_size);
 
+/* reference include/zxc_buffer.h:204 (impl src/lib/zxc_dispatch.c:1234-1242): dictionary id of an archive header, 0 = none */
+ZXC_EXPORT uint32_t zxc_get_dict_id(const void* src, size_t src_size);
+
+/* ---- Block API (no file framing): reference include/zxc_buffer.h:236-362, impl src/lib/zxc_dispatch.c:1627-1858,
+ * bounds src/lib/zxc_common.c:873-902. One block per call = one single-workgroup launch (correct, not fast:
+ * bulk callers use zxc_decompress / the seekable API / zxc_mi355x.h, which decode all blocks in one launch). */
+typedef struct zxc_cctx_s zxc_cctx; /* reference include/zxc_buffer.h:236 */
+typedef struct zxc_dctx_s zxc_dctx; /* :238 */
+ZXC_EXPORT uint64_t zxc_compress_block_bound(size_t input_size);              /* :255  8 + n + 68 + 4, 0 if n = 0 or > 2 MiB */
+ZXC_EXPORT uint64_t zxc_decompress_block_bound(const size_t uncompressed_size); /* :272  n + 2112, 0 if n > 2 MiB */
+/* :300  header(8) + payload [+ checksum(4)]; only level, block_size and checksum_enabled of opts are used
+ * (a dictionary returns ZXC_ERROR_GPU_UNSUPPORTED) */
+ZXC_EXPORT int64_t zxc_compress_block(zxc_cctx* cctx, const void* src, size_t src_size, void* dst,
+                                      size_t dst_capacity, const zxc_compress_opts_t* opts);
+/* :328  dst_capacity in [decoded size, 2 MiB + 2112]; decodes with capacity block_size_ceil(dst_capacity) + 2112 */
+ZXC_EXPORT int64_t zxc_decompress_block(zxc_dctx* dctx, const void* src, size_t src_size, void* dst,
+                                        size_t dst_capacity, const zxc_decompress_opts_t* opts);
+/* :362  strict variant: dst_capacity may equal the decoded size exactly (<= 2 MiB) */
+ZXC_EXPORT int64_t zxc_decompress_block_safe(zxc_dctx* dctx, const void* src, const size_t src_size,
+                                             void* dst, const size_t dst_capacity,
+                                             const zxc_decompress_opts_t* opts);
+
+/* ---- reusable contexts: reference include/zxc_buffer.h:414-486 (impl src/lib/zxc_dispatch.c:1262-1600). Here they
+ * only carry the sticky options; the working memory is the library's per-device arena. */
+ZXC_EXPORT zxc_cctx* zxc_create_cctx(const zxc_compress_opts_t* opts); /* :414  NULL on a bad block size */
+ZXC_EXPORT void zxc_free_cctx(zxc_cctx* cctx);                         /* :421 */
+ZXC_EXPORT int64_t zxc_compress_cctx(zxc_cctx* cctx, const void* src, size_t src_size, void* dst,
+                                     size_t dst_capacity, const zxc_compress_opts_t* opts); /* :448 (sticky opts) */
+ZXC_EXPORT zxc_dctx* zxc_create_dctx(void);                            /* :461 */
+ZXC_EXPORT void zxc_free_dctx(zxc_dctx* dctx);                         /* :468 */
+ZXC_EXPORT int64_t zxc_decompress_dctx(zxc_dctx* dctx, const void* src, size_t src_size, void* dst,
+                                       size_t dst_capacity, const zxc_decompress_opts_t* opts); /* :486 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,12 +30,12 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
             emu::run_wave([&] {
                 zxc_decode_blocks_dict_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size,
                                               verify_trailer ? 4u : 0u, scratch.data(), stride, 0u, busy.data(), n_slots,
-                                              nullptr, dptr, dict_size, dict_huf);
+                                              nullptr, 0u, dptr, dict_size, dict_huf);
             }, b, n_jobs, 64);
         else
             emu::run_wave([&] {
                 zxc_decode_blocks_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size,
-                                         verify_trailer ? 4u : 0u, scratch.data(), stride, 0u, busy.data(), n_slots, nullptr);
+                                         verify_trailer ? 4u : 0u, scratch.data(), stride, 0u, busy.data(), n_slots, nullptr, 0u);
             }, b, n_jobs, 64);
     }
     memcpy(out, o.data() + 4096, out_bytes);

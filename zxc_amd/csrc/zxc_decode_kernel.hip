@@ -1050,7 +1050,7 @@ __device__ __forceinline__ void decode_one_block(const uint8_t* __restrict__ com
                                                  uint32_t n_jobs, uint8_t* __restrict__ out, int32_t* __restrict__ status,
                                                  uint32_t block_size, uint32_t trailer_bytes, uint8_t* __restrict__ scratch,
                                                  uint32_t scratch_stride, uint32_t dbg, uint32_t* __restrict__ slot_busy,
-                                                 uint32_t n_slots, const uint32_t* __restrict__ order,
+                                                 uint32_t n_slots, const uint32_t* __restrict__ order, uint32_t cap_override,
                                                  const uint8_t* __restrict__ dict, uint32_t dict_size,
                                                  const uint8_t* __restrict__ dict_huf) {
     // One workgroup (= one wavefront) per block: the hardware dispatcher hands out blocks as
@@ -1068,7 +1068,9 @@ __device__ __forceinline__ void decode_one_block(const uint8_t* __restrict__ com
 #ifdef EXP_TIMES  // experiment only: status = start (hi 16) and duration (lo 16) in units of 32 ticks of the 100 MHz clock
     const uint64_t t_start = wall_clock64();
 #endif
-    const uint32_t cap = block_size + 2112u;  // the reference always decodes with block_size + ZXC_DECOMPRESS_TAIL_PAD
+    // the reference decodes frames and seekable ranges with block_size + ZXC_DECOMPRESS_TAIL_PAD; only the strict
+    // Block API (zxc_decompress_block_safe, src/lib/zxc_dispatch.c:1815-1858) passes the caller's exact capacity
+    const uint32_t cap = cap_override ? cap_override : block_size + 2112u;
     ScratchPool pool = {scratch, scratch_stride, slot_busy, n_slots, -1};
     const uint64_t comp_off = jobs[b].comp_off;
     const uint32_t src_sz = uni(jobs[b].comp_size);
@@ -1128,9 +1130,10 @@ extern "C" __global__ void __launch_bounds__(64, WAVES_PER_SIMD)
 zxc_decode_blocks_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
                          uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,
                          uint32_t trailer_bytes, uint8_t* __restrict__ scratch, uint32_t scratch_stride, uint32_t dbg,
-                         uint32_t* __restrict__ slot_busy, uint32_t n_slots, const uint32_t* __restrict__ order) {
+                         uint32_t* __restrict__ slot_busy, uint32_t n_slots, const uint32_t* __restrict__ order,
+                         uint32_t cap_override) {
     decode_one_block<false>(comp, jobs, n_jobs, out, status, block_size, trailer_bytes, scratch, scratch_stride, dbg,
-                            slot_busy, n_slots, order, nullptr, 0u, nullptr);
+                            slot_busy, n_slots, order, cap_override, nullptr, 0u, nullptr);
 }
 
 extern "C" __global__ void __launch_bounds__(64, WAVES_PER_SIMD)
@@ -1138,9 +1141,10 @@ zxc_decode_blocks_dict_kernel(const uint8_t* __restrict__ comp, const zxc_dev_jo
                               uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,
                               uint32_t trailer_bytes, uint8_t* __restrict__ scratch, uint32_t scratch_stride, uint32_t dbg,
                               uint32_t* __restrict__ slot_busy, uint32_t n_slots, const uint32_t* __restrict__ order,
-                              const uint8_t* __restrict__ dict, uint32_t dict_size, const uint8_t* __restrict__ dict_huf) {
+                              uint32_t cap_override, const uint8_t* __restrict__ dict, uint32_t dict_size,
+                              const uint8_t* __restrict__ dict_huf) {
     decode_one_block<true>(comp, jobs, n_jobs, out, status, block_size, trailer_bytes, scratch, scratch_stride, dbg,
-                           slot_busy, n_slots, order, dict, dict_size, dict_huf);
+                           slot_busy, n_slots, order, cap_override, dict, dict_size, dict_huf);
 }
 
 // ------------------------------------------------------------------ launch order

@@ -12,7 +12,8 @@
 extern "C" __global__ void zxc_decode_blocks_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                     uint8_t* out, int32_t* status, uint32_t block_size,
                                                     uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride, uint32_t dbg,
-                                                    uint32_t* slot_busy, uint32_t n_slots, const uint32_t* order);
+                                                    uint32_t* slot_busy, uint32_t n_slots, const uint32_t* order,
+                                                    uint32_t cap_override);
 extern "C" __global__ void zxc_order_hist_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                  uint32_t block_size, uint32_t* hist);
 extern "C" __global__ void zxc_order_scatter_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
@@ -21,8 +22,8 @@ extern "C" __global__ void zxc_decode_blocks_dict_kernel(const uint8_t* comp, co
                                                          uint8_t* out, int32_t* status, uint32_t block_size,
                                                          uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride,
                                                          uint32_t dbg, uint32_t* slot_busy, uint32_t n_slots,
-                                                         const uint32_t* order, const uint8_t* dict, uint32_t dict_size,
-                                                         const uint8_t* dict_huf);
+                                                         const uint32_t* order, uint32_t cap_override, const uint8_t* dict,
+                                                         uint32_t dict_size, const uint8_t* dict_huf);
 
 #define ZXC_ENCODE_DECL(name)                                                                                          \
     extern "C" __global__ void name(const uint8_t* src, uint64_t src_size, uint32_t block_size, uint8_t* slots,        \
@@ -37,19 +38,25 @@ extern "C" __global__ void zxc_gather_blocks_kernel(const uint8_t* slots, uint32
 // workgroup. Grown on demand, never shrunk; freed at process exit by the driver.
 #define ZXC_MAX_DEVICES 16
 #define ZXC_ORDER_STREAMS 8
+#define ZXC_POOLS 10 /* block_size_log2 12..21 */
 static struct {
-    uint8_t* scratch;
-    size_t bytes;
+    /* One scratch pool per block size: slot stride and slot count are functions of block_size only, so
+     * concurrent launches on different streams either share a pool with identical geometry (same busy flag
+     * guards the same bytes) or use disjoint pools. Allocated on first use of that block size. */
+    struct { uint8_t* scratch; uint32_t* busy; uint32_t n_slots; uint32_t stride; } pool[ZXC_POOLS];
     int cus;
     int wg_per_cu;
-    uint32_t* counter; /* scratch-slot busy flags */
     /* launch-order buffers ([128 u32 histogram + cursors | order[n]]), one per stream seen: launches on
      * one stream are ordered, so a stream's buffer is free again when its next launch is enqueued */
     struct { void* stream; uint32_t* buf; size_t cap; int used; } ord[ZXC_ORDER_STREAMS];
 } g_dev[ZXC_MAX_DEVICES];
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 
-static uint32_t g_debug_flags = 0;  // timing ablations, set only by zxc_mi355x__set_debug
+#ifdef ZXC_EXPERIMENT  // timing ablations exist only in experiment builds (tools/build_variant.sh); release passes dbg = 0
+static uint32_t g_debug_flags = 0;
+#else
+#define g_debug_flags 0u
+#endif
 
 static int current_device(void) {
     int d = -1;
@@ -59,8 +66,10 @@ static int current_device(void) {
 
 extern "C" {
 
-/* internal (not in include/): kernel timing ablations for tools/kbench.py */
+#ifdef ZXC_EXPERIMENT
+/* experiment builds only (not in include/): kernel timing ablations for tools/kbench.py */
 __attribute__((visibility("default"))) void zxc_mi355x__set_debug(uint32_t flags) { g_debug_flags = flags; }
+#endif
 
 int zxc_mi355x_device_count(void) {
     int n = 0;
@@ -98,7 +107,7 @@ int zxc_mi355x_synchronize(void* stream) {
 
 static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32_t n_jobs, void* d_out,
                          int32_t* d_status, uint32_t block_size, int verify_trailer, void* stream, const void* d_dict,
-                         uint32_t dict_size, const void* d_dict_huf) {
+                         uint32_t dict_size, const void* d_dict_huf, uint32_t cap_override = 0) {
     if (n_jobs == 0) return ZXC_OK;
     if (!d_comp || !d_jobs || !d_out || !d_status) return ZXC_ERROR_NULL_INPUT;
     if (block_size < (1u << 12) || block_size > (1u << 21) || (block_size & (block_size - 1u))) return ZXC_ERROR_BAD_BLOCK_SIZE;
@@ -124,21 +133,28 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
     // Only blocks with an RLE / PivCo section take a slot, waiters spin and holders never wait, so
     // the pool may be smaller than the resident workgroup count: cap it at 1 GiB of scratch.
     const uint32_t max_slots = (uint32_t)g_dev[dev].cus * (uint32_t)g_dev[dev].wg_per_cu;  // <= 8192
-    uint32_t n_slots = (uint32_t)(((size_t)1 << 30) / stride);
-    if (n_slots > max_slots) n_slots = max_slots;
-    if (n_slots < 64u) n_slots = 64u;
-    const size_t need = (size_t)n_slots * stride;
-    if (g_dev[dev].bytes < need) {
-        if (g_dev[dev].scratch) (void)hipFree(g_dev[dev].scratch);
-        g_dev[dev].scratch = NULL;
-        g_dev[dev].bytes = 0;
-        if (hipMalloc((void**)&g_dev[dev].scratch, need) != hipSuccess) return ZXC_ERROR_MEMORY;
-        g_dev[dev].bytes = need;
+    auto& pool = g_dev[dev].pool[__builtin_ctz(block_size) - 12];
+    if (!pool.scratch) {
+        uint32_t n = (uint32_t)(((size_t)1 << 30) / stride);
+        if (n > max_slots) n = max_slots;
+        if (n < 64u) n = 64u;
+        uint8_t* sc = NULL;
+        uint32_t* busy = NULL;
+        if (hipMalloc((void**)&sc, (size_t)n * stride) != hipSuccess) return ZXC_ERROR_MEMORY;
+        if (hipMalloc((void**)&busy, (size_t)n * 4u) != hipSuccess) { (void)hipFree(sc); return ZXC_ERROR_MEMORY; }
+        // slot-busy flags, zero = free (every workgroup releases what it took). The memset runs on the null
+        // stream, which a non-blocking user stream does not wait for: finish it before anyone can launch.
+        if (hipMemset(busy, 0, (size_t)n * 4u) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipFree(sc);
+            (void)hipFree(busy);
+            return ZXC_ERROR_GPU_UNAVAILABLE;
+        }
+        pool.scratch = sc;
+        pool.busy = busy;
+        pool.n_slots = n;
+        pool.stride = stride;
     }
-    if (!g_dev[dev].counter) {  // slot-busy flags, zero = free; every workgroup releases what it took
-        if (hipMalloc((void**)&g_dev[dev].counter, (size_t)8192 * 4u) != hipSuccess) return ZXC_ERROR_MEMORY;
-        if (hipMemset(g_dev[dev].counter, 0, (size_t)8192 * 4u) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
-    }
+    const uint32_t n_slots = pool.n_slots;
     // Heaviest-first dispatch order once the launch spans more than one round of resident workgroups.
     uint32_t* order = NULL;
     if (n_jobs > max_slots && !(g_debug_flags & 0x80000000u)) {
@@ -169,12 +185,12 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
     if (d_dict || d_dict_huf)
         hipLaunchKernelGGL(zxc_decode_blocks_dict_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream,
                            (const uint8_t*)d_comp, d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size,
-                           verify_trailer ? 4u : 0u, g_dev[dev].scratch, stride, g_debug_flags, g_dev[dev].counter, n_slots,
-                           order, (const uint8_t*)d_dict, dict_size, (const uint8_t*)d_dict_huf);
+                           verify_trailer ? 4u : 0u, pool.scratch, stride, g_debug_flags, pool.busy, n_slots,
+                           order, cap_override, (const uint8_t*)d_dict, dict_size, (const uint8_t*)d_dict_huf);
     else
         hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
                            d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, verify_trailer ? 4u : 0u,
-                           g_dev[dev].scratch, stride, g_debug_flags, g_dev[dev].counter, n_slots, order);
+                           pool.scratch, stride, g_debug_flags, pool.busy, n_slots, order, cap_override);
     return hipGetLastError() == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
 }
 
@@ -190,6 +206,18 @@ int zxc_mi355x_decode_blocks_dict_device(const void* d_comp, const zxc_dev_job_t
     return decode_launch(d_comp, d_jobs, n_jobs, d_out, d_status, block_size, verify_trailer, stream, d_dict, dict_size,
                          d_dict_huf);
 }
+
+/* internal to the library (hidden): the host C file's Block API needs the strict capacity of
+ * zxc_decompress_block_safe (cap_override != 0: per-block output cap instead of block_size + 2112) and the
+ * device the calling thread is on (per-device staging arenas). */
+int zxc_hip_decode_blocks(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32_t n_jobs, void* d_out, int32_t* d_status,
+                          uint32_t block_size, int verify_trailer, const void* d_dict, uint32_t dict_size,
+                          const void* d_dict_huf, uint32_t cap_override, void* stream) {
+    if (dict_size > 65535u || (dict_size && !d_dict)) return ZXC_ERROR_DICT_TOO_LARGE;
+    return decode_launch(d_comp, d_jobs, n_jobs, d_out, d_status, block_size, verify_trailer, stream, d_dict, dict_size,
+                         d_dict_huf, cap_override);
+}
+int zxc_hip_current_device(void) { return current_device(); }
 
 uint32_t zxc_mi355x_encode_slot_stride(uint32_t block_size) { return 2u * block_size + 512u; }
 

@@ -14,6 +14,7 @@
  *   zxc_write_seek_table / _size      <- src/lib/zxc_seekable.c:172-214
  */
 #include <limits.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -23,6 +24,7 @@
 #define FORMAT_VERSION 8
 #define BLK_HDR 8
 #define TAIL_PAD 2112u /* ZXC_DECOMPRESS_TAIL_PAD, src/lib/zxc_internal.h:341 */
+#define HOST_BATCH_BYTES ((size_t)256 << 20) /* output slots per launch of the host Buffer API */
 enum { BLK_RAW = 0, BLK_GLO = 1, BLK_GHI = 2, BLK_SEK = 254, BLK_EOF = 255 };
 
 static uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
@@ -191,15 +193,51 @@ uint64_t zxc_get_decompressed_size(const void* src, const size_t src_size) {
 }
 
 /* ------------------------------------------------------- device round trip */
+/* hidden entry points of zxc_hip_shim.hip */
+int zxc_hip_decode_blocks(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32_t n_jobs, void* d_out, int32_t* d_status,
+                          uint32_t block_size, int verify_trailer, const void* d_dict, uint32_t dict_size,
+                          const void* d_dict_huf, uint32_t cap_override, void* stream);
+int zxc_hip_current_device(void);
+
+/* Per-device staging arena: the device buffers of the host API live across calls (grown on demand,
+ * never shrunk), so a call costs its copies and its launch, not four hipMalloc + hipFree (which
+ * synchronise the device). One call at a time per device uses the arena; its mutex is held from
+ * run_jobs() until dev_bufs_free(). */
+typedef struct { void* p; size_t cap; } dbuf_t;
+enum { AR_COMP = 0, AR_JOBS, AR_OUT, AR_STATUS, AR_DICT, AR_N };
+typedef struct {
+    pthread_mutex_t mu;
+    dbuf_t buf[AR_N];
+} arena_t;
+#define HOST_MAX_DEVICES 16
+static arena_t g_arena[HOST_MAX_DEVICES];
+static pthread_once_t g_arena_once = PTHREAD_ONCE_INIT;
+static void arena_init_all(void) {
+    for (int i = 0; i < HOST_MAX_DEVICES; i++) pthread_mutex_init(&g_arena[i].mu, NULL);
+}
+static void* arena_reserve(arena_t* a, int which, size_t need) {
+    dbuf_t* d = &a->buf[which];
+    if (d->cap < need) {
+        zxc_mi355x_free(d->p);
+        d->cap = 0;
+        size_t want = need + (need >> 3) + 4096; /* a little slack: slowly growing callers do not realloc every time */
+        d->p = zxc_mi355x_malloc(want);
+        if (!d->p) { want = need; d->p = zxc_mi355x_malloc(want); }
+        if (d->p) d->cap = want;
+    }
+    return d->p;
+}
+
 /* Decode `n` jobs whose compressed bytes are h_comp[0..comp_bytes) on the host.
- * Output slot i is out_stride bytes at i*out_stride. Leaves statuses in h_status and,
- * on success of the launch, the decoded slots in *d_out_ret (caller frees). */
+ * Output slot i is at jobs[i].out_off. Leaves statuses in h_status and, on success of the
+ * launch, the decoded slots in b->d_out (device memory of the arena: valid until dev_bufs_free(b)). */
 typedef struct {
     void* d_comp;
     void* d_jobs;
     void* d_out;
     void* d_status;
     void* d_dict; /* [dict content | 128-byte shared table] or NULL */
+    arena_t* held;
 } dev_bufs_t;
 
 typedef struct {
@@ -209,50 +247,54 @@ typedef struct {
 } dict_ref_t;
 
 static void dev_bufs_free(dev_bufs_t* b) {
-    zxc_mi355x_free(b->d_comp);
-    zxc_mi355x_free(b->d_jobs);
-    zxc_mi355x_free(b->d_out);
-    zxc_mi355x_free(b->d_status);
-    zxc_mi355x_free(b->d_dict);
+    arena_t* a = b->held;
     memset(b, 0, sizeof(*b));
+    if (a) pthread_mutex_unlock(&a->mu);
 }
 
-static int run_jobs(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_job_t* jobs, uint32_t n,
-                    size_t out_bytes, uint32_t block_size, int verify_trailer, int32_t* h_status,
-                    dev_bufs_t* b, const dict_ref_t* dr) {
+static int run_jobs_cap(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_job_t* jobs, uint32_t n,
+                        size_t out_bytes, uint32_t block_size, uint32_t cap_override, int verify_trailer,
+                        int32_t* h_status, dev_bufs_t* b, const dict_ref_t* dr) {
     memset(b, 0, sizeof(*b));
     if (zxc_mi355x_device_count() <= 0) return ZXC_ERROR_GPU_UNAVAILABLE;
+    const int dev = zxc_hip_current_device();
+    if (dev < 0 || dev >= HOST_MAX_DEVICES) return ZXC_ERROR_GPU_UNAVAILABLE;
+    pthread_once(&g_arena_once, arena_init_all);
+    arena_t* a = &g_arena[dev];
+    pthread_mutex_lock(&a->mu);
+    b->held = a;
     /* +64: the kernel's 16-byte literal / extras reads may run past the last block */
-    b->d_comp = zxc_mi355x_malloc(comp_bytes + 64);
-    b->d_jobs = zxc_mi355x_malloc((size_t)n * sizeof(zxc_dev_job_t));
-    b->d_out = zxc_mi355x_malloc(out_bytes + 64);
-    b->d_status = zxc_mi355x_malloc((size_t)n * sizeof(int32_t));
+    b->d_comp = arena_reserve(a, AR_COMP, comp_bytes + 64);
+    b->d_jobs = arena_reserve(a, AR_JOBS, (size_t)n * sizeof(zxc_dev_job_t));
+    b->d_out = arena_reserve(a, AR_OUT, out_bytes + 64);
+    b->d_status = arena_reserve(a, AR_STATUS, (size_t)n * sizeof(int32_t));
     int rc = ZXC_ERROR_MEMORY;
     if (b->d_comp && b->d_jobs && b->d_out && b->d_status) {
         rc = zxc_mi355x_memcpy_h2d(b->d_comp, h_comp, comp_bytes);
         if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_h2d(b->d_jobs, jobs, (size_t)n * sizeof(zxc_dev_job_t));
         if (rc == ZXC_OK && dr && dr->dict_size) {
-            b->d_dict = zxc_mi355x_malloc(dr->dict_size + ZXC_HUF_TABLE_SIZE + 64);
+            b->d_dict = arena_reserve(a, AR_DICT, dr->dict_size + ZXC_HUF_TABLE_SIZE + 64);
             if (!b->d_dict) rc = ZXC_ERROR_MEMORY;
             if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_h2d(b->d_dict, dr->dict, dr->dict_size);
             if (rc == ZXC_OK && dr->dict_huf)
                 rc = zxc_mi355x_memcpy_h2d((uint8_t*)b->d_dict + dr->dict_size, dr->dict_huf, ZXC_HUF_TABLE_SIZE);
         }
-        if (rc == ZXC_OK) {
-            if (b->d_dict)
-                rc = zxc_mi355x_decode_blocks_dict_device(b->d_comp, (const zxc_dev_job_t*)b->d_jobs, n, b->d_out,
-                                                          (int32_t*)b->d_status, block_size, verify_trailer, b->d_dict,
-                                                          (uint32_t)dr->dict_size,
-                                                          dr->dict_huf ? (uint8_t*)b->d_dict + dr->dict_size : NULL, NULL);
-            else
-                rc = zxc_mi355x_decode_blocks_device(b->d_comp, (const zxc_dev_job_t*)b->d_jobs, n, b->d_out,
-                                                     (int32_t*)b->d_status, block_size, verify_trailer, NULL);
-        }
+        if (rc == ZXC_OK)
+            rc = zxc_hip_decode_blocks(b->d_comp, (const zxc_dev_job_t*)b->d_jobs, n, b->d_out, (int32_t*)b->d_status,
+                                       block_size, verify_trailer, b->d_dict, b->d_dict ? (uint32_t)dr->dict_size : 0u,
+                                       (b->d_dict && dr->dict_huf) ? (uint8_t*)b->d_dict + dr->dict_size : NULL,
+                                       cap_override, NULL);
         if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(NULL);
         if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(h_status, b->d_status, (size_t)n * sizeof(int32_t));
     }
     if (rc != ZXC_OK) dev_bufs_free(b);
     return rc;
+}
+
+static int run_jobs(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_job_t* jobs, uint32_t n,
+                    size_t out_bytes, uint32_t block_size, int verify_trailer, int32_t* h_status,
+                    dev_bufs_t* b, const dict_ref_t* dr) {
+    return run_jobs_cap(h_comp, comp_bytes, jobs, n, out_bytes, block_size, 0u, verify_trailer, h_status, b, dr);
 }
 
 /* ------------------------------------------------------------ zxc_decompress */
@@ -281,84 +323,92 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
     if (dict_size > ZXC_DICT_SIZE_MAX) return ZXC_ERROR_DICT_TOO_LARGE;
     const dict_ref_t dr = {dict, dict_size, dict_huf};
 
-    /* Pass 1 (host): walk the 8-byte block headers into a job table. A problem found
-     * at block k is only reported if blocks 0..k-1 all decode (the reference stops at
-     * the first failure in stream order). */
-    uint32_t cap_jobs = 64, n = 0;
-    zxc_dev_job_t* jobs = (zxc_dev_job_t*)malloc(cap_jobs * sizeof(*jobs));
-    if (!jobs) return ZXC_ERROR_MEMORY;
+    /* The 8-byte block headers are walked on the host into a job table, one bounded batch at a time
+     * (at most HOST_BATCH_BYTES of output slots per launch): device memory is O(batch), not a function
+     * of the untrusted block count, and decoding stops at the first failing or overflowing block like
+     * the reference's sequential loop (zxc_dispatch.c:912-1001). A problem found at block k is only
+     * reported if blocks 0..k-1 all decode (first failure in stream order wins). */
+    uint32_t batch_blocks = (uint32_t)(HOST_BATCH_BYTES / block_size);
+    if (batch_blocks < 16u) batch_blocks = 16u;
+    zxc_dev_job_t* jobs = (zxc_dev_job_t*)malloc((size_t)batch_blocks * sizeof(*jobs));
+    int32_t* st = (int32_t*)malloc((size_t)batch_blocks * sizeof(int32_t));
+    if (!jobs || !st) { free(jobs); free(st); return ZXC_ERROR_MEMORY; }
     size_t ip = ZXC_FILE_HEADER_SIZE;
-    int tail_err = 0;     /* error to report after all queued blocks succeed */
+    int tail_err = 0;         /* error to report after all queued blocks succeed */
     uint32_t global_hash = 0; /* rotl1-xor fold of the stored per-block checksums (zxc_internal.h:1390-1393) */
-    int saw_eof = 0;
-    while (ip < src_size) {
-        const size_t rem = src_size - ip;
-        uint8_t type;
-        uint32_t csz;
-        if (read_block_header(src + ip, rem, &type, &csz) != ZXC_OK) { tail_err = ZXC_ERROR_BAD_HEADER; break; }
-        if (type == BLK_EOF) {
-            if (csz != 0) tail_err = ZXC_ERROR_BAD_HEADER;
-            saw_eof = 1;
-            break;
-        }
-        if (n == cap_jobs) {
-            cap_jobs *= 2;
-            zxc_dev_job_t* nj = (zxc_dev_job_t*)realloc(jobs, cap_jobs * sizeof(*jobs));
-            if (!nj) { free(jobs); return ZXC_ERROR_MEMORY; }
-            jobs = nj;
-        }
-        jobs[n].comp_off = ip;
-        jobs[n].comp_size = rem > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rem; /* wrapper sees all remaining bytes */
-        jobs[n].out_off = (uint64_t)n * block_size;
-        jobs[n].out_len = block_size;
-        n++;
-        if (verify && (size_t)BLK_HDR + csz + 4 <= rem)
-            global_hash = ((global_hash << 1) | (global_hash >> 31)) ^ rd32(src + ip + BLK_HDR + csz);
-        ip += (size_t)BLK_HDR + csz + (file_ck ? 4 : 0);
-    }
-
-    int64_t ret;
+    int saw_eof = 0, done = 0;
+    int64_t ret = 0;
     size_t total = 0;
-    if (n > 0) {
-        int32_t* st = (int32_t*)malloc((size_t)n * sizeof(int32_t));
-        if (!st) { free(jobs); return ZXC_ERROR_MEMORY; }
+    const uint32_t slot = (block_size + TAIL_PAD + 15u) & ~15u;
+    while (!done && ret == 0) {
+        uint32_t n = 0;
+        const size_t span0 = ip;
+        while (n < batch_blocks) {
+            if (ip >= src_size) { done = 1; break; }
+            const size_t rem = src_size - ip;
+            uint8_t type;
+            uint32_t csz;
+            if (read_block_header(src + ip, rem, &type, &csz) != ZXC_OK) { tail_err = ZXC_ERROR_BAD_HEADER; done = 1; break; }
+            if (type == BLK_EOF) {
+                if (csz != 0) tail_err = ZXC_ERROR_BAD_HEADER;
+                saw_eof = 1;
+                done = 1;
+                break;
+            }
+            const uint64_t phys = (uint64_t)BLK_HDR + csz + (file_ck ? 4u : 0u);
+            jobs[n].comp_off = ip - span0;
+            /* the wrapper sees "all remaining bytes"; any size >= the physical block is equivalent */
+            jobs[n].comp_size = (uint32_t)(phys < rem ? phys : rem);
+            jobs[n].out_off = (uint64_t)n * block_size;
+            jobs[n].out_len = block_size;
+            n++;
+            if (verify && phys <= rem)
+                global_hash = ((global_hash << 1) | (global_hash >> 31)) ^ rd32(src + ip + BLK_HDR + csz);
+            if (phys >= rem) { ip = src_size; done = 1; break; }
+            ip += (size_t)phys;
+        }
+        if (n == 0) break;
+        const size_t span = ip - span0;
         dev_bufs_t b;
-        int rc = run_jobs(src, src_size, jobs, n, (size_t)n * block_size, block_size, verify, st, &b, &dr);
-        if (rc != ZXC_OK) { free(st); free(jobs); return rc; }
-        /* sequential semantics: first failing block wins; sizes accumulate in order */
+        int rc = run_jobs(src + span0, span, jobs, n, (size_t)n * block_size, block_size, verify, st, &b, &dr);
+        if (rc != ZXC_OK) { ret = rc; break; }
+        /* sequential semantics: first failing block wins; sizes accumulate in order. A block that is not the
+         * frame's last and decodes to another size than block_size makes the frame irregular (legal, never
+         * produced by the reference encoder): blocks no longer sit back to back in the slot layout. */
         int regular = 1;
-        ret = 0;
+        size_t batch_total = 0;
+        uint32_t good = n;
         for (uint32_t i = 0; i < n; i++) {
-            if (st[i] < 0) { ret = st[i]; break; }
-            if ((size_t)st[i] > dst_capacity - total) { ret = ZXC_ERROR_DST_TOO_SMALL; break; }
-            if ((uint32_t)st[i] != block_size && i + 1 < n) regular = 0;
+            if (st[i] < 0) { ret = st[i]; good = i; break; }
+            if ((size_t)st[i] > dst_capacity - total - batch_total) { ret = ZXC_ERROR_DST_TOO_SMALL; good = i; break; }
+            if ((uint32_t)st[i] != block_size && !(done && i + 1 == n)) regular = 0;
             if ((uint32_t)st[i] > block_size) regular = 0;
-            total += (size_t)st[i];
+            batch_total += (size_t)st[i];
         }
         if (ret == 0 && !regular) {
-            /* Irregular frame (a non-final block shorter/longer than block_size — never
-             * produced by the reference encoder): decoded sizes are a property of the
-             * blocks alone, so re-run with one cap-sized slot per block and gather. */
+            /* decoded sizes are a property of the blocks alone: re-run this batch with one cap-sized slot
+             * per block and gather */
             dev_bufs_free(&b);
-            const uint32_t slot = (block_size + TAIL_PAD + 15u) & ~15u;
             for (uint32_t i = 0; i < n; i++) { jobs[i].out_off = (uint64_t)i * slot; jobs[i].out_len = slot; }
-            rc = run_jobs(src, src_size, jobs, n, (size_t)n * slot, block_size, verify, st, &b, &dr);
-            if (rc != ZXC_OK) { free(st); free(jobs); return rc; }
-            size_t op = 0;
+            rc = run_jobs(src + span0, span, jobs, n, (size_t)n * slot, block_size, verify, st, &b, &dr);
+            if (rc != ZXC_OK) { ret = rc; break; }
+            size_t op = total;
             for (uint32_t i = 0; i < n && rc == ZXC_OK; i++) {
                 rc = zxc_mi355x_memcpy_d2h(dst + op, (const uint8_t*)b.d_out + (size_t)i * slot, (size_t)st[i]);
                 op += (size_t)st[i];
             }
             if (rc != ZXC_OK) ret = rc;
         } else if (ret == 0) {
-            const int crc = zxc_mi355x_memcpy_d2h(dst, b.d_out, total);
+            const int crc = zxc_mi355x_memcpy_d2h(dst + total, b.d_out, batch_total);
             if (crc != ZXC_OK) ret = crc;
         }
+        (void)good;
         dev_bufs_free(&b);
-        free(st);
-        if (ret < 0) { free(jobs); return ret; }
+        total += batch_total;
     }
     free(jobs);
+    free(st);
+    if (ret < 0) return ret;
     if (tail_err) return tail_err;
     if (saw_eof) { /* footer: stored size must equal what was produced (zxc_dispatch.c:936-943) */
         const uint8_t* footer = src + src_size - ZXC_FILE_FOOTER_SIZE;
@@ -655,7 +705,7 @@ int64_t zxc_seekable_decompress_range(zxc_seekable* s, void* dst, const size_t d
     if (len == 0) return 0;
     if (!s || !dst) return ZXC_ERROR_NULL_INPUT;
     if (dst_capacity < len) return ZXC_ERROR_DST_TOO_SMALL;
-    if (offset + len > s->total_decomp) return ZXC_ERROR_SRC_TOO_SMALL;
+    if (offset > s->total_decomp || len > s->total_decomp - offset) return ZXC_ERROR_SRC_TOO_SMALL; /* (no wrap) */
     if (s->dict_id != 0 && (!s->dict || s->dict_size == 0)) return ZXC_ERROR_DICT_REQUIRED;
     const dict_ref_t dr = {s->dict, s->dict_size, s->has_dict_huf ? s->dict_huf : NULL};
 
@@ -724,6 +774,175 @@ int64_t zxc_seekable_decompress_range_mt(zxc_seekable* s, void* dst, const size_
                                          const size_t len, int n_threads) {
     (void)n_threads; /* block-level parallelism is the GPU launch's; CPU threads add nothing */
     return zxc_seekable_decompress_range(s, dst, dst_capacity, offset, len);
+}
+
+
+/* ------------------------------------------------------------ Block API + contexts */
+/* reference include/zxc_buffer.h:204-468; impl src/lib/zxc_dispatch.c:1234-1858, bounds src/lib/zxc_common.c:873-902.
+ * One block per call = one workgroup launch: correct, not fast — callers with many blocks should use the
+ * frame / seekable APIs (one launch for all blocks) or the device-resident entry points of zxc_mi355x.h.
+ * The contexts only carry the sticky options: the working memory of this library lives on the device
+ * (per-device arena above), not in the context. */
+#define BLOCK_FORMAT_OVERHEAD 68u /* ZXC_BLOCK_FORMAT_OVERHEAD, src/lib/zxc_internal.h:427 */
+struct zxc_cctx_s { int level; size_t block_size; int checksum; };
+struct zxc_dctx_s { int unused; };
+
+uint32_t zxc_get_dict_id(const void* src, const size_t src_size) {
+    if (!src || src_size < ZXC_FILE_HEADER_SIZE) return 0;
+    const uint8_t* p = (const uint8_t*)src;
+    if (rd32(p) != MAGIC) return 0;
+    return (p[6] & 0x40) ? rd32(p + 7) : 0;
+}
+
+uint64_t zxc_compress_block_bound(const size_t input_size) {
+    if (input_size == 0 || input_size > ZXC_BLOCK_SIZE_MAX) return 0;
+    return (uint64_t)BLK_HDR + (uint64_t)input_size + BLOCK_FORMAT_OVERHEAD + 4u;
+}
+
+uint64_t zxc_decompress_block_bound(const size_t uncompressed_size) {
+    if (uncompressed_size > ZXC_BLOCK_SIZE_MAX) return 0;
+    return (uint64_t)uncompressed_size + TAIL_PAD;
+}
+
+static size_t block_size_ceil(size_t v) { /* zxc_block_size_ceil, src/lib/zxc_internal.h:885-896 */
+    size_t bs = ZXC_BLOCK_SIZE_MIN;
+    while (bs < v) bs <<= 1;
+    return bs;
+}
+
+zxc_cctx* zxc_create_cctx(const zxc_compress_opts_t* opts) {
+    const size_t bs = (opts && opts->block_size > 0) ? opts->block_size : ZXC_BLOCK_SIZE_DEFAULT;
+    if (bs < ZXC_BLOCK_SIZE_MIN || bs > ZXC_BLOCK_SIZE_MAX || (bs & (bs - 1))) return NULL;
+    zxc_cctx* c = (zxc_cctx*)calloc(1, sizeof(*c));
+    if (!c) return NULL;
+    int level = (opts && opts->level > 0) ? opts->level : ZXC_LEVEL_DEFAULT;
+    c->level = level > ZXC_LEVEL_ULTRA ? ZXC_LEVEL_ULTRA : level;
+    c->block_size = bs;
+    c->checksum = opts ? opts->checksum_enabled : 0;
+    return c;
+}
+void zxc_free_cctx(zxc_cctx* cctx) { free(cctx); }
+zxc_dctx* zxc_create_dctx(void) { return (zxc_dctx*)calloc(1, sizeof(zxc_dctx)); }
+void zxc_free_dctx(zxc_dctx* dctx) { free(dctx); }
+
+/* zxc_compress with sticky options (src/lib/zxc_dispatch.c:1330-1430) */
+int64_t zxc_compress_cctx(zxc_cctx* cctx, const void* src, const size_t src_size, void* dst, const size_t dst_capacity,
+                          const zxc_compress_opts_t* opts) {
+    if (!cctx) return ZXC_ERROR_NULL_INPUT;
+    zxc_compress_opts_t o;
+    memset(&o, 0, sizeof o);
+    if (opts) o = *opts;
+    if (o.level <= 0) o.level = cctx->level;
+    if (o.block_size == 0) o.block_size = cctx->block_size;
+    if (!opts) o.checksum_enabled = cctx->checksum;
+    if (o.level > ZXC_LEVEL_ULTRA) o.level = ZXC_LEVEL_ULTRA;
+    if (o.block_size < ZXC_BLOCK_SIZE_MIN || o.block_size > ZXC_BLOCK_SIZE_MAX || (o.block_size & (o.block_size - 1)))
+        return ZXC_ERROR_BAD_BLOCK_SIZE;
+    cctx->level = o.level;
+    cctx->block_size = o.block_size;
+    cctx->checksum = o.checksum_enabled;
+    return zxc_compress(src, src_size, dst, dst_capacity, &o);
+}
+
+int64_t zxc_decompress_dctx(zxc_dctx* dctx, const void* src, const size_t src_size, void* dst, const size_t dst_capacity,
+                            const zxc_decompress_opts_t* opts) {
+    if (!dctx) return ZXC_ERROR_NULL_INPUT;
+    return zxc_decompress(src, src_size, dst, dst_capacity, opts);
+}
+
+int64_t zxc_compress_block(zxc_cctx* cctx, const void* src, const size_t src_size, void* dst, const size_t dst_capacity,
+                           const zxc_compress_opts_t* opts) {
+    if (!cctx || !src || !dst || src_size == 0 || dst_capacity == 0) return ZXC_ERROR_NULL_INPUT;
+    if (src_size > ZXC_BLOCK_SIZE_MAX) return ZXC_ERROR_BAD_BLOCK_SIZE;
+    const int checksum_enabled = opts ? opts->checksum_enabled : cctx->checksum;
+    int level = (opts && opts->level > 0) ? opts->level : cctx->level;
+    if (level > ZXC_LEVEL_ULTRA) level = ZXC_LEVEL_ULTRA;
+    if (opts && opts->dict && opts->dict_size > 0) return ZXC_ERROR_GPU_UNSUPPORTED; /* dictionary encode: not on the device yet */
+    const size_t want_bs = (opts && opts->block_size > 0) ? opts->block_size : cctx->block_size;
+    const size_t min_bs = block_size_ceil(src_size);
+    const size_t bs = want_bs > min_bs ? want_bs : min_bs; /* one block: block_size >= src_size */
+    if (bs > ZXC_BLOCK_SIZE_MAX || (bs & (bs - 1))) return ZXC_ERROR_BAD_BLOCK_SIZE;
+    cctx->level = level;
+    cctx->block_size = bs;
+    cctx->checksum = checksum_enabled;
+    if (zxc_mi355x_device_count() <= 0) return ZXC_ERROR_GPU_UNAVAILABLE;
+    const uint32_t stride = zxc_mi355x_encode_slot_stride((uint32_t)bs);
+    void* d_src = zxc_mi355x_malloc(src_size + 64);
+    void* d_slot = zxc_mi355x_malloc(stride);
+    void* d_size = zxc_mi355x_malloc(4);
+    int64_t rc = ZXC_ERROR_MEMORY;
+    uint32_t csize = 0;
+    if (d_src && d_slot && d_size) {
+        rc = zxc_mi355x_memcpy_h2d(d_src, src, src_size);
+        if (rc == ZXC_OK)
+            rc = zxc_mi355x_encode_blocks_device(d_src, src_size, (uint32_t)bs, level, checksum_enabled, d_slot,
+                                                 (uint32_t*)d_size, NULL);
+        if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(NULL);
+        if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(&csize, d_size, 4);
+        if (rc == ZXC_OK && csize > dst_capacity) rc = ZXC_ERROR_DST_TOO_SMALL;
+        if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(dst, d_slot, csize);
+    }
+    zxc_mi355x_free(d_src);
+    zxc_mi355x_free(d_slot);
+    zxc_mi355x_free(d_size);
+    return rc == ZXC_OK ? (int64_t)csize : rc;
+}
+
+/* One block -> dst. `cap_override` 0: decode capacity block_size_ceil(dst_capacity) + 2112 like the
+ * reference's work_buf bounce (zxc_dispatch.c:1745-1790); else the strict capacity of the safe variant. */
+static int64_t decompress_one_block(const void* src, size_t src_size, void* dst, size_t dst_capacity,
+                                    const zxc_decompress_opts_t* opts, uint32_t cap_override) {
+    const int verify = opts ? opts->checksum_enabled : 0;
+    const uint8_t* dict = opts ? (const uint8_t*)opts->dict : NULL;
+    const size_t dict_size = (opts && opts->dict) ? opts->dict_size : 0;
+    if (dict_size > ZXC_DICT_SIZE_MAX) return ZXC_ERROR_DICT_TOO_LARGE;
+    const dict_ref_t dr = {dict, dict_size, (opts && opts->dict) ? (const uint8_t*)opts->dict_huf : NULL};
+    size_t bs = block_size_ceil(dst_capacity);
+    if (bs > ZXC_BLOCK_SIZE_MAX) bs = ZXC_BLOCK_SIZE_MAX;
+    const size_t work = cap_override ? cap_override : bs + TAIL_PAD;
+    zxc_dev_job_t job;
+    job.comp_off = 0;
+    job.out_off = 0;
+    job.comp_size = src_size > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)src_size;
+    job.out_len = (uint32_t)(dst_capacity < work ? dst_capacity : work);
+    int32_t st = 0;
+    dev_bufs_t b;
+    /* only the block itself is uploaded: header + payload (+ trailer), never more than the caller's buffer */
+    size_t up = src_size;
+    if (src_size >= BLK_HDR) {
+        const uint64_t phys = (uint64_t)BLK_HDR + rd32((const uint8_t*)src + 3) + 4u;
+        if (phys < up) up = (size_t)phys;
+    }
+    int rc = run_jobs_cap((const uint8_t*)src, up, &job, 1, ((size_t)job.out_len + 15u) & ~(size_t)15u, (uint32_t)bs, cap_override,
+                          verify, &st, &b, &dr);
+    if (rc != ZXC_OK) return rc;
+    int64_t ret = st;
+    if (st > 0) {
+        if ((size_t)st > dst_capacity) ret = ZXC_ERROR_DST_TOO_SMALL;
+        else {
+            rc = zxc_mi355x_memcpy_d2h(dst, b.d_out, (size_t)st);
+            if (rc != ZXC_OK) ret = rc;
+        }
+    }
+    dev_bufs_free(&b);
+    return ret;
+}
+
+int64_t zxc_decompress_block(zxc_dctx* dctx, const void* src, const size_t src_size, void* dst, const size_t dst_capacity,
+                             const zxc_decompress_opts_t* opts) {
+    if (!dctx || !src || !dst || src_size < BLK_HDR || dst_capacity == 0) return ZXC_ERROR_NULL_INPUT;
+    if (dst_capacity > (size_t)ZXC_BLOCK_SIZE_MAX + TAIL_PAD) return ZXC_ERROR_BAD_BLOCK_SIZE;
+    return decompress_one_block(src, src_size, dst, dst_capacity, opts, 0u);
+}
+
+int64_t zxc_decompress_block_safe(zxc_dctx* dctx, const void* src, const size_t src_size, void* dst,
+                                  const size_t dst_capacity, const zxc_decompress_opts_t* opts) {
+    if (!dctx || !src || !dst || src_size < BLK_HDR || dst_capacity == 0) return ZXC_ERROR_NULL_INPUT;
+    if (dst_capacity > ZXC_BLOCK_SIZE_MAX) return ZXC_ERROR_BAD_BLOCK_SIZE;
+    /* dictionary inputs and RAW blocks take the bounce-capable path (zxc_dispatch.c:1823-1832) */
+    if ((opts && opts->dict && opts->dict_size > 0) || ((const uint8_t*)src)[0] == BLK_RAW)
+        return zxc_decompress_block(dctx, src, src_size, dst, dst_capacity, opts);
+    return decompress_one_block(src, src_size, dst, dst_capacity, opts, (uint32_t)dst_capacity);
 }
 
 #include "zxc_stream_host.inc"
