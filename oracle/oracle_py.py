@@ -185,3 +185,62 @@ class Ref:
         rc = self.lib.zxc_seekable_decompress_range_mt(s, out, length, offset, length, threads)
         self.lib.zxc_seekable_free(s)
         return rc, (out.raw[:max(rc, 0)] if dst is None else b"")
+
+
+def bind_block_api(L):
+    """Block API + contexts (reference include/zxc_buffer.h:204-486): the same prototypes bind the reference
+    .so and the product libzxc_mi355x.so."""
+    L.zxc_get_dict_id.restype = C.c_uint32
+    L.zxc_get_dict_id.argtypes = [C.c_char_p, C.c_size_t]
+    for f in ("zxc_compress_block_bound", "zxc_decompress_block_bound"):
+        getattr(L, f).restype = C.c_uint64
+        getattr(L, f).argtypes = [C.c_size_t]
+    L.zxc_create_cctx.restype = C.c_void_p
+    L.zxc_create_cctx.argtypes = [C.POINTER(CompressOpts)]
+    L.zxc_free_cctx.argtypes = [C.c_void_p]
+    L.zxc_create_dctx.restype = C.c_void_p
+    L.zxc_create_dctx.argtypes = []
+    L.zxc_free_dctx.argtypes = [C.c_void_p]
+    L.zxc_compress_block.restype = C.c_int64
+    L.zxc_compress_block.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(CompressOpts)]
+    L.zxc_compress_cctx.restype = C.c_int64
+    L.zxc_compress_cctx.argtypes = L.zxc_compress_block.argtypes
+    for f in ("zxc_decompress_block", "zxc_decompress_block_safe", "zxc_decompress_dctx"):
+        getattr(L, f).restype = C.c_int64
+        getattr(L, f).argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(DecompressOpts)]
+    return L
+
+
+class BlockApi:
+    """Thin helper over either library's Block API (one cctx + one dctx, reused)."""
+
+    def __init__(self, lib):
+        self.L = bind_block_api(lib)
+        self.c = self.L.zxc_create_cctx(None)
+        self.d = self.L.zxc_create_dctx()
+        assert self.c and self.d
+
+    def close(self):
+        self.L.zxc_free_cctx(self.c)
+        self.L.zxc_free_dctx(self.d)
+        self.c = self.d = None
+
+    def compress_block(self, data, level=3, checksum=False, block_size=0):
+        o = CompressOpts(level=level, checksum_enabled=int(checksum), block_size=block_size)
+        cap = int(self.L.zxc_compress_block_bound(len(data))) or 64
+        dst = C.create_string_buffer(cap)
+        rc = self.L.zxc_compress_block(self.c, data, len(data), dst, cap, C.byref(o))
+        return rc, dst.raw[:max(rc, 0)]
+
+    def decompress_block(self, blk, cap, checksum=False, safe=False, dict_=None, dict_huf=None):
+        o = DecompressOpts(checksum_enabled=int(checksum))
+        keep = None
+        if dict_:
+            keep = (C.create_string_buffer(dict_, len(dict_)), C.create_string_buffer(dict_huf, 128) if dict_huf else None)
+            o.dict = C.cast(keep[0], C.c_void_p)
+            o.dict_size = len(dict_)
+            o.dict_huf = C.cast(keep[1], C.c_void_p) if dict_huf else None
+        out = C.create_string_buffer(max(cap, 1))
+        fn = self.L.zxc_decompress_block_safe if safe else self.L.zxc_decompress_block
+        rc = fn(self.d, blk, len(blk), out, cap, C.byref(o))
+        return rc, out.raw[:max(rc, 0)]

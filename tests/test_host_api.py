@@ -48,6 +48,23 @@ def test_compress_bound_matches_reference(product, ref):
         assert product.lib().zxc_compress_bound(n) == ref.lib.zxc_compress_bound(n)
 
 
+def test_block_bounds_and_dict_id_match_reference(product, ref):
+    """zxc_compress_block_bound / zxc_decompress_block_bound (src/lib/zxc_common.c:873-902) and zxc_get_dict_id
+    (src/lib/zxc_dispatch.c:1234-1242) are pure host arithmetic: same numbers as the reference."""
+    import oracle_py
+    P = oracle_py.bind_block_api(product.lib())
+    Rl = oracle_py.bind_block_api(ref.lib)
+    for n in (0, 1, 4095, 4096, 65536, (1 << 21) - 1, 1 << 21, (1 << 21) + 1, 1 << 30):
+        assert P.zxc_compress_block_bound(n) == Rl.zxc_compress_block_bound(n), n
+        assert P.zxc_decompress_block_bound(n) == Rl.zxc_decompress_block_bound(n), n
+    for f in sorted(os.listdir(os.path.join(GOLDEN, "conformance", "valid"))):
+        if f.endswith(".zxc"):
+            b = read(f"conformance/valid/{f}")
+            assert P.zxc_get_dict_id(b, len(b)) == Rl.zxc_get_dict_id(b, len(b)), f
+            assert (P.zxc_get_dict_id(b, len(b)) != 0) == f.startswith("dict_")
+    assert P.zxc_get_dict_id(b"\0" * 16, 16) == 0 and P.zxc_get_dict_id(b"", 0) == 0
+
+
 def test_container_errors_need_no_gpu(product, manifest):
     """Header-level rejections happen on the host before any device work, with the
     reference's pinned codes (conformance/test_conformance.c:228-249)."""
