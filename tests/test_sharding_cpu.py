@@ -85,3 +85,74 @@ def test_range_helpers():
     costs = [1, 100, 1, 1, 100, 1, 1, 1]
     rr = shard.byte_balanced_ranges(2, costs)
     assert rr[0][0] == 0 and rr[-1][1] == len(costs) and rr[0][1] == rr[1][0]
+
+
+def _bench_worker(rank, world, port, q, tiles_per_gpu):
+    """bench.py's own partition code on CPU tensors: rank_partition -> build_rank_corpus (reference-encoded tiles,
+    only the ones the range touches) -> all_gather of the seek-table entries (control plane) -> ONE seek table
+    opened through zxc_seekable_open_reader -> zxc_mi355x_plan_seekable(first, n, comp_rebase); the rank's jobs
+    are then decoded with the oracle straight from its own compressed span."""
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    import bench
+    import oracle_py
+    from zxc_amd import corpus
+    corpus.TILE_BYTES = 5 * 65536      # small tiles for the CPU rehearsal (the GPU bench uses 3234 blocks per tile)
+    corpus.CHUNK_BYTES = 2 * 65536
+    bs = 65536
+    n_total, first, last = bench.rank_partition(rank, world, tiles_per_gpu, bs)
+    d_comp, my_sizes, d_want, hdr, eof, prep, _ = bench.build_rank_corpus(first, last, 3, bs, None, torch.device("cpu"))
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, my_sizes.tobytes())
+        all_sizes = np.concatenate([np.frombuffer(b, dtype=np.uint32) for b in gathered])
+    else:
+        all_sizes = my_sizes
+    s = bench.open_global_table(all_sizes, bs, hdr, eof, n_total * bs)
+    assert s.num_blocks == n_total
+    rebase = 16 + int(all_sizes[:first].astype(np.int64).sum())
+    jobs = s.plan(first, last - first, rebase)
+    comp = d_comp.numpy().tobytes()
+    o = oracle_py.Oracle()
+    out = bytearray()
+    for j in jobs:
+        rc, b = o.decode_block(comp[int(j["comp_off"]):int(j["comp_off"]) + int(j["comp_size"])], bs)
+        assert rc == int(j["out_len"]) == bs
+        out += b
+    assert bytes(out) == d_want.numpy().tobytes()
+    res = (rank, first, last, all_sizes.tobytes(), bytes(out))
+    if world > 1:
+        allres = [None] * world
+        dist.all_gather_object(allres, res)
+        if rank == 0:
+            q.put(allres)
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        q.put([res])
+
+
+def test_bench_partition_is_one_seek_table(ref):
+    """2 ranks x 2 tiles and 1 rank x 4 tiles are the SAME corpus and the SAME seek table; the two ranks'
+    ranges are disjoint, contiguous, and together decode to what the single rank decodes."""
+    ctx = mp.get_context("spawn")
+    results = {}
+    for world, tiles in ((2, 2), (1, 4)):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q, tiles)) for r in range(world)]
+        for p in procs:
+            p.start()
+        results[world] = sorted(q.get(timeout=300))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    two, one = results[2], results[1]
+    assert two[0][3] == two[1][3] == one[0][3]                       # one table, identical on every rank and at N = 1
+    assert two[0][1] == 0 and two[0][2] == two[1][1] and two[1][2] == one[0][2] == 20
+    assert two[0][4] + two[1][4] == one[0][4]

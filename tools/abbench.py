@@ -1,28 +1,31 @@
 #!/usr/bin/env python3
 """A/B of library variants on the bench workload (GPU box only): python tools/abbench.py libA.so libB.so ...
-Builds the workload once per process (bench.build_workload), times the decode launch, checks the bytes."""
+The parent prepares AB_TILES corpus tiles once (bench.build_rank_corpus on the CPU, saved under /tmp); one child
+per variant loads them, times the decode launch (best of 3 x 5) and checks every byte.
+Env: AB_TILES (3), AB_LEVEL (3)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+TMP = "/tmp/zxc_abbench"
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
-    sys.path.insert(0, ROOT)
-    import numpy as np, torch, zxc_amd, bench
-    mib = int(os.environ.get("AB_MIB", "64")); R = int(os.environ.get("AB_REPL", "32")); level = int(os.environ.get("AB_LEVEL", "3"))
-    data, comp, prep = bench.build_workload(mib << 20, level, 65536)
-    s = zxc_amd.Seekable(comp); nb = s.num_blocks; total = s.decompressed_size
-    base = s.plan(); dev = torch.device("cuda", 0)
-    cs = (len(comp) + 255) & ~255; osz = (total + 255) & ~255
-    d_comp = torch.empty(R * cs + 256, dtype=torch.uint8, device=dev)
-    h = torch.frombuffer(bytearray(comp), dtype=torch.uint8)
-    for r in range(R): d_comp[r*cs:r*cs+len(comp)].copy_(h)
-    jobs = np.tile(base, R); rep = np.repeat(np.arange(R, dtype=np.uint64), nb)
-    jobs["comp_off"] += rep * np.uint64(cs); jobs["out_off"] += rep * np.uint64(osz)
+    import numpy as np, torch, zxc_amd
+    level = int(os.environ.get("AB_LEVEL", "3"))
+    dev = torch.device("cuda", 0)
+    comp = np.load(f"{TMP}/comp.npy"); sizes = np.load(f"{TMP}/sizes.npy"); want = np.load(f"{TMP}/want.npy")
+    n = sizes.size
+    jobs = np.zeros(n, dtype=zxc_amd.api.JOB_DTYPE)
+    jobs["comp_size"] = sizes
+    jobs["comp_off"] = np.concatenate([[0], np.cumsum(sizes.astype(np.uint64))[:-1]])
+    jobs["out_off"] = np.arange(n, dtype=np.uint64) * 65536
+    jobs["out_len"] = 65536
+    d_comp = torch.from_numpy(comp).to(dev); d_want = torch.from_numpy(want).to(dev)
     d_jobs = torch.frombuffer(bytearray(jobs.tobytes()), dtype=torch.uint8).to(dev)
-    d_out = torch.zeros(R * osz + 256, dtype=torch.uint8, device=dev)
-    d_st = torch.zeros(jobs.size, dtype=torch.int32, device=dev)
+    d_out = torch.zeros(n * 65536 + 256, dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    def step(): zxc_amd.decode_blocks_device(d_comp.data_ptr(), d_jobs.data_ptr(), jobs.size, d_out.data_ptr(), d_st.data_ptr(), 65536, False, stream)
+    def step(): zxc_amd.decode_blocks_device(d_comp.data_ptr(), d_jobs.data_ptr(), n, d_out.data_ptr(), d_st.data_ptr(), 65536, False, stream)
     step(); step(); torch.cuda.synchronize()
-    ok = bool((d_st.cpu().numpy() == jobs["out_len"].astype(np.int32)).all()) and bytes(d_out[(R-1)*osz:(R-1)*osz+total].cpu().numpy()) == data
+    ok = bool((d_st == 65536).all().item()) and torch.equal(d_out[:n * 65536], d_want)
     best = 1e9
     for _ in range(3):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -30,8 +33,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         for _ in range(5): step()
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 5)
-    print(f"{os.environ.get('ZXC_LIB_VARIANT','libzxc_mi355x.so'):24s} L{level} ok={ok} {best:7.3f} ms {R*total/best/1e6:8.1f} GB/s", flush=True)
+    ok = ok and torch.equal(d_out[:n * 65536], d_want)
+    print(f"{os.environ.get('ZXC_LIB_VARIANT','libzxc_mi355x.so'):28s} L{level} blocks {n} ok={ok} {best:7.3f} ms {n*65536/best/1e6:8.1f} GB/s", flush=True)
 else:
+    import multiprocessing as mp
+    import numpy as np, torch, bench
+    from zxc_amd import corpus
+    tiles = int(os.environ.get("AB_TILES", "3")); level = int(os.environ.get("AB_LEVEL", "3"))
+    os.makedirs(TMP, exist_ok=True)
+    with mp.get_context("spawn").Pool(min(32, os.cpu_count() or 1)) as pool:
+        d_comp, sizes, d_want, *_ = bench.build_rank_corpus(0, tiles * corpus.TILE_BLOCKS, level, 65536, pool, torch.device("cpu"))
+    np.save(f"{TMP}/comp.npy", d_comp.numpy()); np.save(f"{TMP}/sizes.npy", sizes); np.save(f"{TMP}/want.npy", d_want.numpy())
     for lib in sys.argv[1:]:
         env = dict(os.environ); env["ZXC_LIB_VARIANT"] = lib
         subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=env)

@@ -5,9 +5,9 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=$1
-CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
-timeout -k 5 120 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_kt -o kt --output-format csv -- $CMD > $R/gpurun_out/${tag}_kt.log 2>&1
-timeout -k 5 120 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${tag}_fetch -o f --output-format csv -- $CMD > $R/gpurun_out/${tag}_fetch.log 2>&1
-timeout -k 5 120 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${tag}_write -o w --output-format csv -- $CMD > $R/gpurun_out/${tag}_write.log 2>&1
-timeout -k 5 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES -d $R/gpurun_out/${tag}_sq -o s --output-format csv -- $CMD > $R/gpurun_out/${tag}_sq.log 2>&1
+CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --calib $PROFILE_BENCH_ARGS"
+timeout -k 5 ${PROFILE_TIMEOUT:-300} rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_kt -o kt --output-format csv -- $CMD > $R/gpurun_out/${tag}_kt.log 2>&1
+timeout -k 5 ${PROFILE_TIMEOUT:-300} rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${tag}_fetch -o f --output-format csv -- $CMD > $R/gpurun_out/${tag}_fetch.log 2>&1
+timeout -k 5 ${PROFILE_TIMEOUT:-300} rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${tag}_write -o w --output-format csv -- $CMD > $R/gpurun_out/${tag}_write.log 2>&1
+timeout -k 5 ${PROFILE_TIMEOUT:-300} rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES -d $R/gpurun_out/${tag}_sq -o s --output-format csv -- $CMD > $R/gpurun_out/${tag}_sq.log 2>&1
 ls $R/gpurun_out/${tag}_*/

@@ -32,6 +32,13 @@ class _DecompressOpts(C.Structure):  # include/zxc_opts.h
                 ("user_data", C.c_void_p)]
 
 
+_READ_AT = C.CFUNCTYPE(C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64)
+
+
+class _Reader(C.Structure):  # zxc_reader_t, include/zxc_seekable.h
+    _fields_ = [("read_at", _READ_AT), ("ctx", C.c_void_p), ("size", C.c_uint64)]
+
+
 def lib_path():
     return os.path.join(_HERE, os.environ.get("ZXC_LIB_VARIANT", "libzxc_mi355x.so"))  # variant: A/B builds for tools/
 
@@ -62,6 +69,8 @@ def lib():
         L.zxc_seekable_open.restype = C.c_void_p
         L.zxc_seekable_open.argtypes = [C.c_char_p, C.c_size_t]
         L.zxc_seekable_free.argtypes = [C.c_void_p]
+        L.zxc_seekable_open_reader.restype = C.c_void_p
+        L.zxc_seekable_open_reader.argtypes = [C.POINTER(_Reader)]
         for f in ("zxc_seekable_get_num_blocks",):
             getattr(L, f).restype = C.c_uint32
             getattr(L, f).argtypes = [C.c_void_p]
@@ -133,9 +142,26 @@ def decompress(comp: bytes, capacity=None, checksum=False, raise_on_error=True, 
 class Seekable:
     """zxc_seekable handle (include/zxc_seekable.h). Keeps `comp` alive: the C handle borrows it."""
 
-    def __init__(self, comp: bytes):
+    def __init__(self, comp: bytes = None, reader=None, size=None):
+        """`comp`: the whole archive in memory (zxc_seekable_open). `reader(offset, length) -> bytes` + `size`:
+        zxc_seekable_open_reader — only header, seek table and footer are read at open, so an archive whose
+        blocks live elsewhere (e.g. each GPU holding its own block range) can still be opened as ONE table."""
         self._comp = comp
-        self._h = lib().zxc_seekable_open(comp, len(comp))
+        if reader is not None:
+            def _cb(_ctx, dst, n, off):
+                try:
+                    b = reader(int(off), int(n))
+                    if b is None or len(b) != n:
+                        return -11  # ZXC_ERROR_IO
+                    C.memmove(dst, b, n)
+                    return n
+                except Exception:
+                    return -11
+            self._cb = _READ_AT(_cb)
+            self._rd = _Reader(self._cb, None, int(size))
+            self._h = lib().zxc_seekable_open_reader(C.byref(self._rd))
+        else:
+            self._h = lib().zxc_seekable_open(comp, len(comp))
         if not self._h:
             raise ZxcError(-6, "zxc_seekable_open (not a seekable archive)")
 

@@ -266,3 +266,52 @@ def period300(n: int, seed: int = 7) -> bytes:
     """300-byte random period: forces 16-bit offsets with long matches."""
     p = _rng(seed, 300).integers(0, 256, 300, dtype=np.uint8).tobytes()
     return (p * (n // 300 + 1))[:n]
+
+
+# ---- tiled corpus for the benchmark (SURVEY.md §8(d): "tiled with a per-tile 64-bit xor-rotated seed so no two
+# tiles are identical") -------------------------------------------------------------------------------------
+# One tile = silesia.tar's class mix, cut to a whole number of 64 KiB blocks, so tiles (and the archives made
+# from them) concatenate into ONE seekable corpus whose block i lives in tile i // TILE_BLOCKS. A tile is
+# generated in independent chunks of at most CHUNK_BYTES (own generator state each), so that a process pool
+# fills it in parallel; tile t of seed s is always the same bytes whatever the pool size.
+TILE_BLOCKS = SILESIA_BYTES // 65536          # 3234 blocks of 64 KiB
+TILE_BYTES = TILE_BLOCKS * 65536              # 211 943 424 B (silesia.tar's size minus its last 4096 B)
+CHUNK_BYTES = 8 << 20
+
+
+def tile_seed(tile: int, seed: int = 0) -> int:
+    """64-bit xor-rotated per-tile seed."""
+    x = (_GOLDEN ^ ((tile + 1) * 0xD6E8FEB86659FD93) ^ seed) & _MASK
+    r = 17 + (tile % 31)
+    return ((x << r) | (x >> (64 - r))) & _MASK
+
+
+def tile_chunks(tile: int, seed: int = 0):
+    """[(class, n_bytes, rng_seed, rng_segment)] — the independent pieces of one tile, in layout order."""
+    ts = tile_seed(tile, seed)
+    total = sum(f for _, f in _SILESIA_MIX)
+    out = []
+    done = 0
+    for i, (cls, frac) in enumerate(_SILESIA_MIX):
+        m = TILE_BYTES - done if i == len(_SILESIA_MIX) - 1 else int(TILE_BYTES * frac / total)
+        done += m
+        k = 0
+        while m > 0:
+            c = min(m, CHUNK_BYTES)
+            out.append((cls, c, ts, i * 64 + k))
+            m -= c
+            k += 1
+    return out
+
+
+def gen_chunk(task) -> bytes:
+    """Pool worker: one chunk of a tile (numpy only, no GPU state)."""
+    cls, n, ts, seg = task
+    return np.ascontiguousarray(_GEN[cls](n, _rng(ts, seg))[:n]).tobytes()
+
+
+def synth_silesia_tile(tile: int, seed: int = 0, pool=None) -> bytes:
+    """TILE_BYTES bytes of tile `tile` (pool: anything with .map, e.g. multiprocessing.Pool)."""
+    tasks = tile_chunks(tile, seed)
+    parts = pool.map(gen_chunk, tasks) if pool is not None else [gen_chunk(t) for t in tasks]
+    return b"".join(parts)

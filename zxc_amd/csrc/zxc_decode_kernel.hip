@@ -63,6 +63,9 @@ typedef v4u __attribute__((aligned(1))) v4u_unaligned;
 #ifndef MATCH_MED
 #define MATCH_MED 128u   // matches up to this long are copied lane-per-sequence (16-byte grid steps)
 #endif
+#ifndef FAR_EARLY
+#define FAR_EARLY 0      // 1: far-source groups requested unconditionally, before the literal wait (A/B)
+#endif
 #define BYTEWISE_MAX 32u // short-period overlapping matches up to this long: lane-local byte loop
 
 // zxc_error_t values (reference include/zxc_error.h:38-74)
@@ -663,6 +666,18 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             // these, and the literal puts run under the round trip.
             const bool pf = pending && need == 0ull && stepable && farsrc && sg + 32u <= O.out_pad;
             v4u fr0 = {0, 0, 0, 0}, fr1 = {0, 0, 0, 0};
+#if FAR_EARLY
+            // Both groups are requested by EVERY lane (lanes without a far source read the block's first 32
+            // bytes: one cache line, no divergence), right behind the literal loads and without waiting for
+            // anything: a wave's own stores and loads reach L2 in program order, so the flush stores that wrote
+            // those bytes are ahead of these loads, and with a fixed number of younger loads the compiler waits
+            // for the literal data with vmcnt(2) — the far round trip runs under the literal puts.
+            {
+                const uint8_t* fa = O.dst + (pf ? sg : 0u);
+                fr0 = __builtin_nontemporal_load((const v4u_unaligned*)fa);
+                fr1 = __builtin_nontemporal_load((const v4u_unaligned*)(fa + 16u));
+            }
+#else
             // (unconditional wait: the literal data is needed next anyway, and with every older access known to
             // be complete on both paths the compiler does not force these loads to finish before the literal puts)
             __builtin_amdgcn_s_waitcnt(0);  // also: the flush stores that wrote those bytes have landed
@@ -671,6 +686,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                 fr0 = __builtin_nontemporal_load((const v4u_unaligned*)(O.dst + sg));
                 if (me > 16u) fr1 = __builtin_nontemporal_load((const v4u_unaligned*)(O.dst + sg + 16u));
             }
+#endif
             PH(2);
             // ---- literals, part 2: one masked ds_or group per 16 bytes of grid
             {
