@@ -52,7 +52,7 @@ def test_block_bounds_and_dict_id_match_reference(product, ref):
     """zxc_compress_block_bound / zxc_decompress_block_bound (src/lib/zxc_common.c:873-902) and zxc_get_dict_id
     (src/lib/zxc_dispatch.c:1234-1242) are pure host arithmetic: same numbers as the reference."""
     import oracle_py
-    P = oracle_py.bind_block_api(product.lib())
+    P = oracle_py.bind_block_api(C.CDLL(product.lib_path()))
     Rl = oracle_py.bind_block_api(ref.lib)
     for n in (0, 1, 4095, 4096, 65536, (1 << 21) - 1, 1 << 21, (1 << 21) + 1, 1 << 30):
         assert P.zxc_compress_block_bound(n) == Rl.zxc_compress_block_bound(n), n

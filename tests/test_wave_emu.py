@@ -87,3 +87,57 @@ def test_levels_and_block_sizes_on_emulator(emu, oracle, ref):
     data = corpus.synth_silesia(96 << 10, seed=4) + corpus.small_offset_pattern(3000) + bytes(5000) + corpus.period300(9000)
     for level, bs in ((1, 4096), (2, 16384), (3, 8192), (4, 4096), (5, 16384), (6, 8192), (7, 16384)):
         _check_archive(emu, oracle, ref.compress(data, level, bs, True, level == 4), verify=True)
+
+
+# ------------------------------------------------------------------ encode kernels on the emulator
+def _enc_roundtrip(emu, ref, oracle, data, level, bs=65536, checksum=False):
+    comp = emu.encode(data, level, bs, checksum=checksum)
+    rc, out = ref.decompress(comp, len(data), checksum=checksum)
+    assert rc == len(data) and out == data, ("reference decoder", level, len(data), rc)
+    rc, out = oracle.decompress(comp, len(data), checksum=checksum)
+    assert rc == len(data) and out == data
+    return comp
+
+
+def test_encoder_levels_on_emulator(emu, ref, oracle, synth_inputs):
+    """The hash-chain match finder + GLO / GHI serialiser, every level, on the CPU wave emulator: archives
+    round-trip through the UNMODIFIED reference decoder; levels 1-2 emit GHI (type 2), 3-7 GLO (type 1); size within
+    5 % of the reference encoder at levels 3 and 5; identical bytes on a second run (deterministic tables)."""
+    data = synth_inputs["mixed_384k"][:196608]
+    sizes = {}
+    for level in range(1, 8):
+        comp = _enc_roundtrip(emu, ref, oracle, data, level)
+        sizes[level] = len(comp)
+        t = oracle.seek_table(comp)
+        types = {comp[o] for o in t["comp_offsets"][:t["n_blocks"]]}
+        assert types <= ({0, 2} if level <= 2 else {0, 1}), (level, types)
+    for level in (3, 5):
+        assert sizes[level] <= 1.05 * len(ref.compress(data, level, 65536, True, False)), (level, sizes)
+    assert sizes[5] < sizes[3] < sizes[1]
+    assert emu.encode(data, 3, 65536) == emu.encode(data, 3, 65536)
+
+
+def test_encoder_edge_cases_on_emulator(emu, ref, oracle):
+    rng = random.Random(5)
+    for n in (0, 1, 15, 63, 64, 65, 4095, 4097, 65535, 65536, 65537):
+        data = bytes(rng.getrandbits(8) & (0x0F if n % 2 else 0xFF) for _ in range(n))
+        _enc_roundtrip(emu, ref, oracle, data, 3)
+        _enc_roundtrip(emu, ref, oracle, data, 1, checksum=True)
+    _enc_roundtrip(emu, ref, oracle, bytes(150000), 3)                       # zeros: long overlapping matches
+    _enc_roundtrip(emu, ref, oracle, b"abcdefghij" * 9000, 5, 131072)
+    _enc_roundtrip(emu, ref, oracle, b"ABCDE" * 3000, 2, 4096)
+
+
+def test_encoder_rle_literals_on_emulator(emu, ref, oracle):
+    """Runs shorter than the LZ minimum match survive as literals; the literal section is then RLE-coded
+    (enc_lit = 1) like the reference's golden case 11 (tests/format/golden_cases.h:152-165)."""
+    s, b = 0x1357BD13, bytearray(16384)
+    for i in range(0, len(b), 5):
+        s = (s * 1103515245 + 12345) & 0xFFFFFFFF
+        b[i] = s >> 24
+        for k in range(1, 5):
+            if i + k < len(b):
+                b[i + k] = 0xAA
+    comp = _enc_roundtrip(emu, ref, oracle, bytes(b), 3)
+    assert comp[16] == 1 and comp[16 + 8 + 8] == 1, "GLO block with enc_lit = 1 expected"
+    assert len(comp) <= 1.10 * len(ref.compress(bytes(b), 3, 65536, True, False))

@@ -43,6 +43,50 @@ class Emu:
         jobs["out_len"] = np.minimum(bs, total - np.arange(n, dtype=np.int64) * bs).astype(np.uint32)
         return jobs, *self.decode_jobs(comp, jobs, total, bs, verify_trailer=bool(table["has_checksum"]) and kw.pop("verify", False), **kw)
 
+    def encode(self, data: bytes, level=3, block_size=65536, checksum=False, seekable=True) -> bytes:
+        """The encode kernels on the emulator, one wavefront per block, assembled into a v8 archive the way
+        zxc_compress (zxc_host.c) does: file header, blocks, EOF block, optional seek table, footer."""
+        import oracle_py
+        L = self.lib
+        L.emu_encode_slot_stride.restype = C.c_uint32
+        L.emu_encode_blocks.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        nb = (len(data) + block_size - 1) // block_size
+        stride = L.emu_encode_slot_stride(block_size)
+        slots = C.create_string_buffer(max(nb * stride, 1))
+        sizes = np.zeros(max(nb, 1), dtype=np.uint32)
+        if nb:
+            L.emu_encode_blocks(data, len(data), block_size, level, int(checksum), slots, sizes.ctypes.data)
+        O = oracle_py.Oracle().lib
+        O.zxo_hash16.argtypes = [C.c_char_p]
+        O.zxo_hash8.argtypes = [C.c_char_p]
+        hdr = bytearray(16)
+        hdr[0:4] = (0x9CB02EF5).to_bytes(4, "little")
+        hdr[4] = 8
+        hdr[5] = block_size.bit_length() - 1
+        hdr[6] = 0x80 if checksum else 0
+        hdr[14:16] = int(O.zxo_hash16(bytes(hdr))).to_bytes(2, "little")
+        out = bytearray(hdr)
+        gh = 0
+        raw = slots.raw
+        for b in range(nb):
+            blk = raw[b * stride: b * stride + int(sizes[b])]
+            out += blk
+            if checksum:
+                gh = (((gh << 1) | (gh >> 31)) & 0xFFFFFFFF) ^ int.from_bytes(blk[-4:], "little")
+        eof = bytearray(8)
+        eof[0] = 255
+        eof[7] = O.zxo_hash8(bytes(eof))
+        out += eof
+        if seekable and nb:
+            sek = bytearray(8)
+            sek[0] = 254
+            sek[3:7] = (4 * nb).to_bytes(4, "little")
+            sek[7] = O.zxo_hash8(bytes(sek))
+            out += sek + sizes[:nb].astype("<u4").tobytes()
+        out += len(data).to_bytes(8, "little") + (gh if checksum else 0).to_bytes(4, "little")
+        self.last_sizes = sizes[:nb].copy()
+        return bytes(out)
+
 
 def frame_jobs(comp: bytes):
     """Walks the block headers of a (seekable or plain) archive the way the host API does:

@@ -35,7 +35,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         best = min(best, e0.elapsed_time(e1) / 5)
     ok = ok and torch.equal(d_out[:n * 65536], d_want)
     print(f"{os.environ.get('ZXC_LIB_VARIANT','libzxc_mi355x.so'):28s} L{level} blocks {n} ok={ok} {best:7.3f} ms {n*65536/best/1e6:8.1f} GB/s", flush=True)
-else:
+elif __name__ == "__main__":
     import multiprocessing as mp
     import numpy as np, torch, bench
     from zxc_amd import corpus

@@ -212,7 +212,7 @@ _SILESIA_MIX = [
     ("source", 0.025),   # xml
     ("image16", 0.040),  # x-ray
 ]
-_GEN = {"text": gen_text, "exe": gen_exe, "image16": gen_image16, "chem": gen_chem,
+_GEN = {"enwik": None, "text": gen_text, "exe": gen_exe, "image16": gen_image16, "chem": gen_chem,
         "records": gen_records, "source": gen_source, "catalogue": gen_catalogue}
 
 SILESIA_BYTES = 211947520
@@ -304,6 +304,24 @@ def tile_chunks(tile: int, seed: int = 0):
     return out
 
 
+def gen_enwik(n: int, rng) -> np.ndarray:
+    """enwik9-like chunk: 80 % text + 20 % XML / source (config 3, the match-finder workload)."""
+    a = gen_text(int(n * 0.8), rng)
+    b = gen_source(n - a.size, rng)
+    return np.concatenate([a, b])[:n]
+
+
+def enwik_chunks(n: int, seed: int = 1):
+    """[(class, n_bytes, rng_seed, rng_segment)] covering n bytes of unique enwik-like text in CHUNK_BYTES pieces."""
+    out, k = [], 0
+    while n > 0:
+        c = min(n, CHUNK_BYTES)
+        out.append(("enwik", c, tile_seed(k, seed), k))
+        n -= c
+        k += 1
+    return out
+
+
 def gen_chunk(task) -> bytes:
     """Pool worker: one chunk of a tile (numpy only, no GPU state)."""
     cls, n, ts, seg = task
@@ -315,3 +333,6 @@ def synth_silesia_tile(tile: int, seed: int = 0, pool=None) -> bytes:
     tasks = tile_chunks(tile, seed)
     parts = pool.map(gen_chunk, tasks) if pool is not None else [gen_chunk(t) for t in tasks]
     return b"".join(parts)
+
+
+_GEN["enwik"] = gen_enwik

@@ -590,7 +590,11 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             const bool mine = (uint32_t)lane < k;
             const uint32_t tile_end = (uint32_t)__builtin_amdgcn_readlane((int)E, (int)(k - 1u));
             const uint32_t z_new = (tile_end + 15u) & ~15u;
+#ifdef EXP_NO_FAR  // experiment only (wrong output): every source is taken from the ring — the launch time with no read-back traffic at all
+            const uint32_t ring_lo = 0u;
+#else
             const uint32_t ring_lo = z_new > RING_BYTES ? z_new - RING_BYTES : 0u;
+#endif
             if (z_new > z_end) {
                 ring_zero(L, z_end, z_new, lane);
                 z_end = z_new;

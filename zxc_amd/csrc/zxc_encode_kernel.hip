@@ -1,25 +1,35 @@
-// zxc_encode_kernel.hip — per-block LZ77 match finder + GLO serialiser for gfx950.
+// zxc_encode_kernel.hip — per-block LZ77 hash-chain match finder + GLO / GHI serialiser for gfx950.
 //
 // Reference being replaced: zxc_compress_chunk_wrapper (src/lib/zxc_compress.c:2041-2074) →
-// zxc_encode_block_glo (:1124-1799) whose hot loop is zxc_lz77_find_best_match (:185-547): one
-// thread walks the block, hashing 5 bytes into a 32 K-entry head table + 64 K-entry chain,
-// with lazy probes at ip+1/ip+2. That loop is inherently sequential (what gets inserted depends
-// on what was matched), so it is NOT reproduced; the wire format only requires what the decoder
-// checks (docs/FORMAT.md §5.2): min match 5, 1 <= offset <= 65535 and
-// <= bytes produced, token/varint escapes, >= 32 bytes behind the literals, RAW if not smaller.
+// zxc_encode_block_glo (:1124-1799) / zxc_encode_block_ghi (:1820-1987), whose hot loop is
+// zxc_lz77_find_best_match (:185-547): head table + chain table walked for at most search_depth
+// candidates, stop at sufficient_len, backward extension to the anchor, lazy probes at ip+1 / ip+2
+// (per-level parameters src/lib/zxc_internal.h:965-979). The CPU loop is sequential (what gets inserted
+// depends on what was matched); here the SAME search structure is filled and walked 64 positions at a time:
 //
-// One wavefront per block. 64 positions per step, one per lane:
-//   1. hash of 5 bytes -> LDS table of most recent positions (ds_max_u32: "latest wins",
-//      deterministic), candidate verified and extended with 8-byte XOR + ctz compares;
-//   2. every lane publishes its position (atomicMax) for later chunks;
-//   3. the scalar unit walks the chunk's match lengths with v_readlane: greedy with a one-step
-//      lazy probe; a match that reaches past the chunk makes the wave skip whole chunks;
-//   4. selected lanes emit token / offset / varints at wave-prefix-sum positions; bytes not
-//      covered by a match stream into the literal section, one byte per lane (prefix popcount).
-// Finally the sections are slid together into the reference's GLO layout, or the block is stored
-// RAW when that is not smaller. Output is a valid v8 block for every level (levels select the
-// CPU's parse effort; this matcher has one strategy), round-trip-checked by tests/ against the
-// unmodified reference decoder.
+// One wavefront per block, 64 positions per step, one per lane:
+//   1. hash (5 bytes, or 4 bytes at levels 1-2, the reference's two hash functions) -> head[] in LDS = the
+//      most recent position with that hash; chain[] in LDS (a ring over the last 2^CWB positions) links every
+//      position to the previous one with the same hash. EVERY position is inserted (the CPU inserts only the
+//      positions its parse visits), so a chain here is denser than the reference's and needs fewer steps;
+//   2. each lane walks its own chain for up to `depth` candidates, three per round: the links are LDS reads,
+//      the three candidates' 16 bytes are requested together (one memory round trip per round), compared
+//      with 64-bit XOR + ctz, the longest kept; a candidate that matches all 16 bytes is extended 8 bytes at
+//      a time; the walk stops at `sufficient` bytes like the reference's;
+//   3. the chunk's positions are published: chain link = distance to the old head, head = own position; lanes
+//      that share a bucket resolve it deterministically (highest position wins, re-checked until stable);
+//   4. the scalar unit walks the chunk's match lengths with v_readlane: greedy parse with the level's lazy
+//      probes (ip+1, ip+2), each accepted match extended backwards over equal preceding bytes down to the
+//      previous match's end (the reference's backtrack); a match that reaches past the chunk makes the wave
+//      skip whole chunks;
+//   5. selected lanes emit token / offset / varints (GLO) or 32-bit sequence words (GHI, levels 1-2) at
+//      wave-prefix-sum positions; bytes not covered by a match stream into the literal section.
+// Finally the literal section is RLE-coded when that is smaller by the reference's margin
+// (zxc_compress.c:1270-1534, :1671-1722), the sections are slid together into the reference's layout, or
+// the block is stored RAW when that is not smaller. Levels differ in effort (table sizes, chain depth,
+// sufficient length, lazy probes: table at the bottom). Not done here: the level-6/7 optimal parse and
+// PivCo literal / token coding (levels 6-7 emit GLO with RAW / RLE literals). Output is a valid v8 block,
+// round-trip-checked by tests/ against the unmodified reference decoder; archive bytes are deterministic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -81,31 +91,61 @@ __device__ __forceinline__ uint8_t hdr_hash8(uint64_t v) {
     return (uint8_t)((h >> 32) ^ h);
 }
 
-// wave copy of n bytes, forward, dst below src (regions may overlap that way): every step
-// loads 1 KiB, waits, then stores it
-__device__ void wave_move_down(uint8_t* dst, const uint8_t* src, uint32_t n, int lane) {
+// wave copy of n bytes, forward, dst below src (regions may overlap that way). Every step moves 1 KiB: the
+// wave's loads of a step precede its stores (one instruction each), and a step's stores end below the next
+// step's loads because dst < src — no waits beyond the data dependence are needed.
+__device__ __forceinline__ void wave_move_down(uint8_t* dst, const uint8_t* src, uint32_t n, int lane) {
     const uint32_t full = n & ~15u;
-    for (uint32_t o = 16u * lane; o < full; o += 1024u) {
-        const v4u v = e_ld128(src + o);
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_memcpy(dst + o, &v, 16);
-        __builtin_amdgcn_s_waitcnt(0);
+    for (uint32_t base = 0; base < full; base += 1024u) {
+        const uint32_t o = base + 16u * (uint32_t)lane;
+        v4u v = {0, 0, 0, 0};
+        if (o < full) v = e_ld128(src + o);
+        __builtin_amdgcn_wave_barrier();
+        if (o < full) __builtin_memcpy(dst + o, &v, 16);
+        __builtin_amdgcn_wave_barrier();
     }
     uint32_t tb = 0;
     if (full + (uint32_t)lane < n) tb = src[full + lane];
-    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
     if (full + (uint32_t)lane < n) dst[full + lane] = (uint8_t)tb;
-    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// common prefix (bytes, 0..16) of two 16-byte groups
+__device__ __forceinline__ uint32_t prefix16(uint64_t a_lo, uint64_t a_hi, const v4u c) {
+    const uint64_t x = a_lo ^ ((uint64_t)c.x | ((uint64_t)c.y << 32));
+    const uint64_t xh = a_hi ^ ((uint64_t)c.z | ((uint64_t)c.w << 32));
+    if (x) return (uint32_t)(__builtin_ctzll(x) >> 3);
+    if (xh) return 8u + (uint32_t)(__builtin_ctzll(xh) >> 3);
+    return 16u;
+}
+// a candidate whose first 16 bytes match: extend 8 bytes at a time (src/lib/zxc_compress.c:270-330), up to the block end
+__device__ __forceinline__ uint32_t extend_match(const uint8_t* in, uint32_t i, uint32_t c, uint32_t n) {
+    uint32_t len = 16;
+    while (i + len + 8u <= n) {
+        const uint64_t y = e_ld64(in + i + len) ^ e_ld64(in + c + len);
+        if (y) return len + (uint32_t)(__builtin_ctzll(y) >> 3);
+        len += 8u;
+    }
+    while (i + len < n && in[i + len] == in[c + len]) len++;
+    return len;
 }
 
 // Slot layout while encoding (stride = 2*block_size + 512 bytes per block):
-//   [0,8) block header | [8,20) GLO header | literals ... | ... staging: tokens, offsets, extras
-template <uint32_t ENC_HBITS>
+//   [0,8) block header | [8,20) GLO/GHI header | literals ... | ... staging from block_size + 64: tokens (GLO: 1 B,
+//   GHI: 4-byte words), offsets (GLO), extras
+// HB = log2(head entries), CWB = log2(chain ring entries) or 0 for "head only". depth / sufficient / lazy: the
+// reference's search_depth / sufficient_len / lazy probes (src/lib/zxc_internal.h:965-979), see the table below.
+template <uint32_t HB, uint32_t CWB, bool GHI>
 __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src, uint64_t src_size, uint32_t block_size,
                                                  uint8_t* __restrict__ slots, uint32_t slot_stride,
-                                                 uint32_t* __restrict__ sizes, uint32_t n_blocks, uint32_t with_checksum) {
-    constexpr uint32_t ENC_HSIZE = 1u << ENC_HBITS;
-    __shared__ uint16_t ht[ENC_HSIZE];
+                                                 uint32_t* __restrict__ sizes, uint32_t n_blocks, uint32_t with_checksum,
+                                                 uint32_t depth, uint32_t sufficient, uint32_t lazy) {
+    constexpr uint32_t HSIZE = 1u << HB;
+    constexpr uint32_t CW = CWB ? (1u << CWB) : 1u;
+    constexpr uint32_t CWM = CW - 1u;
+    __shared__ uint16_t ht[HSIZE];     // head: low 16 bits of the most recent position with this hash
+    __shared__ uint16_t chain[CW];     // chain[q & CWM]: distance from q to the previous position with q's hash (0: none)
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) return;
@@ -116,18 +156,20 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     uint8_t* slot = slots + (uint64_t)b * slot_stride;
     uint8_t* lit_out = slot + 20;
     const uint32_t max_seq = block_size / 5u + 16u;
-    uint8_t* tok_st = slot + block_size + 64u;
-    uint8_t* off_st = tok_st + max_seq;       // u16 per sequence
-    uint8_t* ext_st = off_st + 2u * max_seq;  // <= 6 bytes per sequence would not fit worst case; bounded below
+    uint8_t* tok_st = slot + block_size + 64u;                // GLO: 1 byte per sequence; GHI: one 32-bit word
+    uint8_t* off_st = tok_st + max_seq;                       // GLO: u16 per sequence
+    uint8_t* ext_st = GHI ? tok_st + 4u * max_seq : off_st + 2u * max_seq;
+    const uint32_t ext_cap = GHI ? block_size / 8u : block_size / 4u;  // staging bound; beyond it the block goes RAW
+    const uint32_t esc = GHI ? 255u : 15u;                    // token escape value (LL and ML - 5)
 
-    for (uint32_t i = lane; i < ENC_HSIZE / 2u; i += 64u) ((uint32_t*)ht)[i] = 0u;
+    for (uint32_t i = lane; i < HSIZE / 2u; i += 64u) ((uint32_t*)ht)[i] = 0u;
+    if (CWB) for (uint32_t i = lane; i < CW / 2u; i += 64u) ((uint32_t*)chain)[i] = 0u;
     __syncthreads();
 
     uint32_t seq_count = 0, lit_count = 0, ext_count = 0, max_off = 0;
     uint32_t pos = 0;     // next position the parse will look at
     uint32_t anchor = 0;  // end of the last emitted match
     const uint32_t limit = n > ENC_MARGIN + 8u ? n - ENC_MARGIN - 8u : 0u;  // last position that may start a match (exclusive)
-    const uint32_t ext_cap = block_size / 4u;                                // staging bound; beyond it the block goes RAW
     bool overflow = false;
 
     uint32_t c0 = 0;
@@ -136,11 +178,8 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     uint32_t c_next = 0;
     while (c0 < n) {
         const uint32_t i = c0 + (uint32_t)lane;
-        // ---- 1. candidate + verified length for every position of the chunk
-        uint32_t len = 0, cpos = 0;
-        uint64_t v = 0, vh = 0;
         const bool can = i < limit;
-        uint32_t h = 0;
+        uint64_t v = 0, vh = 0;
         if (c_next != c0 && can) v_next = e_ld128(in + i);  // (a long match skipped ahead: the prefetch was for another chunk)
         {   // request the following chunk's bytes now; they arrive while this chunk is matched, parsed and emitted
             v = (uint64_t)v_next.x | ((uint64_t)v_next.y << 32);
@@ -149,41 +188,78 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             const uint32_t i2 = c_next + (uint32_t)lane;
             if (i2 < limit) v_next = e_ld128(in + i2);
         }
+        // ---- 1. hash -> head candidate (zxc_hash_func, src/lib/zxc_compress.c:45-53: 5-byte / 4-byte variants)
+        uint32_t h = 0, d0 = 0;
         if (can) {
-            h = (uint32_t)(((v & 0xFFFFFFFFFFull) * 0x9E3779B185EBCA87ull) >> (64u - ENC_HBITS));
-            const uint32_t dist = (i - (uint32_t)ht[h]) & 0xFFFFu;
-            {
-                cpos = i - dist;
-                if (dist != 0u && dist <= i) {
-                    // 16 bytes of both sides in one round trip: most matches end inside them
-                    const v4u cv = e_ld128(in + cpos);
-                    const uint64_t x = v ^ ((uint64_t)cv.x | ((uint64_t)cv.y << 32));
-                    const uint64_t xh = vh ^ ((uint64_t)cv.z | ((uint64_t)cv.w << 32));
-                    if (x == 0 && xh != 0) {
-                        len = 8u + (uint32_t)(__builtin_ctzll(xh) >> 3);
-                    } else if (x == 0) {
-                        len = 16;
-                        while (i + len + 8u <= n) {  // extend, 8 bytes at a time
-                            const uint64_t y = e_ld64(in + i + len) ^ e_ld64(in + cpos + len);
-                            if (y) { len += (uint32_t)(__builtin_ctzll(y) >> 3); break; }
-                            len += 8u;
-                        }
-                        if (len > n - i) len = n - i;
-                        while (i + len < n && in[i + len] == in[cpos + len]) len++;
-                    } else {
-                        len = (uint32_t)(__builtin_ctzll(x) >> 3);
-                    }
-                    if (len < 5u) len = 0;
-                }
+            if (GHI) h = (((uint32_t)v ^ ((uint32_t)v >> 15)) * 0x2D35182Du) >> (32u - HB);
+            else h = (uint32_t)(((v & 0xFFFFFFFFFFull) * 0x2545F4914F6CDD1Dull) >> (64u - HB));
+            d0 = (i - (uint32_t)ht[h]) & 0xFFFFu;  // entries hold 16 bits of a position; every candidate is verified
+            if (d0 > i) d0 = 0;                    // (0: none)
+        }
+        // ---- 2. chain walk, three candidates per round (zxc_lz77_find_best_match :262-440)
+        uint32_t len = 0, dist = 0, tried = 0, d = d0;
+        for (;;) {
+            const bool act = d != 0u && tried < depth && len < sufficient;
+            if (__ballot(act) == 0ull) break;
+            uint32_t da = act ? d : 0u, db = 0, dc = 0, dn = 0;
+            if (CWB) {
+                // a link is still in the ring while no newer position has taken its slot
+                auto next = [&](uint32_t dk, bool want) -> uint32_t {
+                    if (!want || dk == 0u || dk + 64u - (uint32_t)lane > CW) return 0u;
+                    const uint32_t dl = chain[(i - dk) & CWM];
+                    const uint32_t r = dk + dl;
+                    return (dl != 0u && r <= 0xFFFFu && r <= i) ? r : 0u;
+                };
+                db = next(da, tried + 1u < depth);
+                dc = next(db, tried + 2u < depth);
+                dn = next(dc, tried + 3u < depth);
+            }
+            v4u ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0}, cc = {0, 0, 0, 0};
+            if (da) ca = e_ld128(in + i - da);
+            if (db) cb = e_ld128(in + i - db);
+            if (dc) cc = e_ld128(in + i - dc);
+            uint32_t ma = da ? prefix16(v, vh, ca) : 0u, mb = db ? prefix16(v, vh, cb) : 0u, mc = dc ? prefix16(v, vh, cc) : 0u;
+            if (ma == 16u) ma = extend_match(in, i, i - da, n);
+            if (mb == 16u && ma < sufficient) mb = extend_match(in, i, i - db, n);
+            if (mc == 16u && ma < sufficient && mb < sufficient) mc = extend_match(in, i, i - dc, n);
+            if (ma > len) { len = ma; dist = da; }   // (first = nearest wins ties: smaller offsets, cheaper tokens)
+            if (mb > len) { len = mb; dist = db; }
+            if (mc > len) { len = mc; dist = dc; }
+            tried += 3u;
+            d = dn;
+        }
+        if (len > n - i) len = n - i;
+        if (len < 5u) { len = 0; dist = 0; }
+        // backward extension available at this position: equal bytes just before both sides (<= 16)
+        uint32_t bk = 0;
+        if (len && i >= 16u && i - dist >= 16u) {
+            const uint64_t y = e_ld64(in + i - 8u) ^ e_ld64(in + i - dist - 8u);
+            const uint64_t y2 = e_ld64(in + i - 16u) ^ e_ld64(in + i - dist - 16u);
+            bk = y ? (uint32_t)(__builtin_clzll(y) >> 3) : (y2 ? 8u + (uint32_t)(__builtin_clzll(y2) >> 3) : 16u);
+        }
+        // ---- 3. publish this chunk's positions: lookups above saw only earlier chunks
+        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        if (can && CWB) chain[i & CWM] = (uint16_t)d0;
+        // head: the highest position of a bucket must win whatever order the hardware applies colliding stores in
+        {
+            bool want = can;
+            for (;;) {
+                if (want) ht[h] = (uint16_t)i;
+                __syncthreads();
+                const uint32_t behind = can ? ((i - (uint32_t)ht[h]) & 0xFFFFu) : 0u;  // 0: mine is in; 1..63: an earlier lane's
+                want = behind != 0u && behind < 64u;
+                if (__ballot(want) == 0ull) break;
+                __syncthreads();
             }
         }
-        // ---- 2. publish this chunk's positions (most recent wins)
-        if (can) ht[h] = (uint16_t)i;
         __syncthreads();
 
-        // ---- 3. scalar parse of the chunk
+        // ---- 4. scalar parse of the chunk: greedy + the level's lazy probes + backward extension
         uint64_t sel = 0;
+        uint32_t ext_v = 0;  // per selected lane: bytes its match grew backwards
         uint32_t p = pos > c0 ? pos - c0 : 0u;
+        uint32_t floor_p = p;  // chunk positions below this are consumed
         const uint64_t has = __ballot(len >= 5u);  // positions where a match starts
         const uint32_t pend = (n - c0 < 64u) ? n - c0 : 64u;
         while (p < pend) {
@@ -192,50 +268,69 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             p += (uint32_t)__builtin_ctzll(ahead);
             if (p >= pend) { p = pend; break; }
             const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)p);
-            const uint32_t L1 = (p + 1u < 64u) ? (uint32_t)__builtin_amdgcn_readlane((int)len, (int)(p + 1u)) : 0u;
-            if (L1 > L + 1u) { p++; continue; }  // lazy: a clearly longer match starts one byte later
+            if (lazy >= 1u && L < 128u) {  // (lazy_len_threshold 128)
+                const uint32_t L1 = (p + 1u < 64u) ? (uint32_t)__builtin_amdgcn_readlane((int)len, (int)(p + 1u)) : 0u;
+                if (L1 > L + 1u) { p++; continue; }  // a clearly longer match starts one byte later
+                if (lazy >= 2u) {
+                    const uint32_t L2 = (p + 2u < 64u) ? (uint32_t)__builtin_amdgcn_readlane((int)len, (int)(p + 2u)) : 0u;
+                    if (L2 > L + 2u) { p += 2u; continue; }
+                }
+            }
+            uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)bk, (int)p);
+            e = e < p - floor_p ? e : p - floor_p;
+            ext_v = ((uint32_t)lane == p) ? e : ext_v;  // (v_cmp + v_cndmask with scalar sources)
             sel |= 1ull << p;
             p += L;
+            floor_p = p;
         }
         const uint32_t next_pos = c0 + p;
 
-        // ---- 4. emit sequences and literals
+        // ---- 5. emit sequences and literals
         const bool issel = (sel >> lane) & 1ull;
-        // end of the previous selected match (or the carried anchor)
         const uint64_t below = sel & lt_mask;
         const int prevlane = below ? 63 - __builtin_clzll(below) : 0;
-        const uint32_t prev_end = __shfl(i + len, prevlane);
+        const uint32_t prev_end = __shfl(i + len, prevlane);       // end of the previous selected match (or the carried anchor)
         const uint32_t lit_start = below ? prev_end : anchor;
-        const uint32_t ll = issel ? i - lit_start : 0u;
-        const uint32_t mlm = issel ? len - 5u : 0u;
-        const uint32_t off = i - cpos;
+        const uint32_t mstart = i - ext_v;                          // where my match starts after growing backwards
+        const uint32_t ll = issel ? mstart - lit_start : 0u;
+        const uint32_t mlm = issel ? len + ext_v - 5u : 0u;
         uint32_t eb = 0;
-        if (issel) eb = (ll >= 15u ? varint_len(ll - 15u) : 0u) + (mlm >= 15u ? varint_len(mlm - 15u) : 0u);
+        if (issel) eb = (ll >= esc ? varint_len(ll - esc) : 0u) + (mlm >= esc ? varint_len(mlm - esc) : 0u);
         const uint32_t eincl = e_scan_add(eb);
         const uint32_t etot = (uint32_t)__builtin_amdgcn_readlane((int)eincl, 63);
         const uint32_t nsel = __popcll(sel);
         if (seq_count + nsel > max_seq || ext_count + etot > ext_cap) { overflow = true; break; }
         if (issel) {
             const uint32_t sidx = seq_count + __popcll(below);
-            tok_st[sidx] = (uint8_t)(((ll < 15u ? ll : 15u) << 4) | (mlm < 15u ? mlm : 15u));
-            const uint16_t o16 = (uint16_t)(off - 1u);
-            __builtin_memcpy(off_st + 2u * sidx, &o16, 2);
+            if (GHI) {  // 32-bit word LL(8) | ML-5(8) | offset-1(16), src/lib/zxc_compress.c:1907-1913
+                const uint32_t w = ((ll < 255u ? ll : 255u) << 24) | ((mlm < 255u ? mlm : 255u) << 16) | ((dist - 1u) & 0xFFFFu);
+                __builtin_memcpy(tok_st + 4u * sidx, &w, 4);
+            } else {
+                tok_st[sidx] = (uint8_t)(((ll < 15u ? ll : 15u) << 4) | (mlm < 15u ? mlm : 15u));
+                const uint16_t o16 = (uint16_t)(dist - 1u);
+                __builtin_memcpy(off_st + 2u * sidx, &o16, 2);
+            }
             uint8_t* e = ext_st + ext_count + eincl - eb;
-            if (ll >= 15u) { put_varint(e, ll - 15u); e += varint_len(ll - 15u); }
-            if (mlm >= 15u) put_varint(e, mlm - 15u);
+            if (ll >= esc) { put_varint(e, ll - esc); e += varint_len(ll - esc); }
+            if (mlm >= esc) put_varint(e, mlm - esc);
         }
         // only the 8-bit / 16-bit offset decision needs the maximum: one ballot instead of a wave reduction
-        if (__ballot(issel && off > 256u)) max_off = 65535u;
+        if (__ballot(issel && dist > 256u)) max_off = 65535u;
         else if (sel && max_off == 0u) max_off = 1u;
-        // coverage: selected matches are disjoint and in order, so a position is covered exactly when it lies
-        // before the end of the last selected match at or below it (or of the match carried into the chunk)
-        uint32_t cover_until = pos;  // positions < pos are covered by a match that started earlier
+        // coverage: selected matches are disjoint and in order. A position is inside a match when it lies before the
+        // end of the last selected match at or below it (or of the match carried into the chunk), or at / after the
+        // (backwards grown) start of the next selected match above it.
+        uint32_t cover_until = pos;
         {
             const uint32_t endv = issel ? i + len : (below ? prev_end : 0u);
             cover_until = endv > cover_until ? endv : cover_until;
         }
+        const uint64_t above = sel & ~(lt_mask | (1ull << lane));
+        const int nextlane = above ? __builtin_ctzll(above) : 0;
+        const uint32_t next_start = __shfl(mstart, nextlane);
+        const bool in_next = above != 0ull && i >= next_start;
         // literal = in range, not inside a match, and already passed by the parse
-        const bool islit = i < n && i >= cover_until && i < next_pos;
+        const bool islit = i < n && i >= cover_until && i < next_pos && !in_next;
         const uint64_t litmask = __ballot(islit);
         // (the byte is already here: low byte of the 16 fetched for this position; only the block's last 16
         // positions, which never start a match, were not fetched)
@@ -254,12 +349,109 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     }
     __builtin_amdgcn_s_waitcnt(0);
 
-    // ---- assemble: [8 B block header][12 B GLO header][literals][tokens][offsets][extras][pad]
-    const bool off8 = max_off <= 256u && max_off != 0u;
-    const uint32_t sz_off = off8 ? seq_count : 2u * seq_count;
-    uint32_t behind = seq_count + sz_off + ext_count;
+    // ---- RLE literal coding (GLO only): token < 0x80 copies token+1 raw bytes, >= 0x80 repeats the next byte
+    // (token & 0x7F) + 4 times (src/lib/zxc_decompress.c:906-975). Chosen when rle_size + 3.125 % of the literal
+    // count (below level 6; zxc_internal.h:771-773) beats the raw section. Segmentation as the reference writes it
+    // (zxc_compress.c:1671-1722): maximal runs of >= 4 equal bytes become 2-byte run tokens in chunks of <= 131
+    // (a remainder of 1-3 bytes is a raw token of its own), everything between them raw tokens of <= 128 bytes.
+    uint32_t rle_size = 0;
+    bool use_rle = false;
+    if (!GHI && !overflow && lit_count >= 64u) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the literal section is read back with cached loads
+        uint8_t* rle_out = lit_out + lit_count + 4u;         // (temp behind the literals; moved down when chosen)
+        const bool room = 24u + 2u * lit_count + 8u <= block_size + 64u;
+        // pass 0 sizes, pass 1 writes
+        for (uint32_t pass = 0; pass < 2u && room; pass++) {
+            if (pass == 1u) {
+                const uint32_t tax = (lit_count * 8u) >> 8;  // ZXC_SS_TAX(lit_c, 8)
+                if (!(rle_size + tax < lit_count)) break;
+                use_rle = true;
+            }
+            // wave-uniform walk over maximal runs: E bit j of a 64-byte tile = "byte j equals byte j + 1"
+            uint32_t w = 0;            // bytes written / sized so far
+            uint32_t seg_start = 0;    // first literal byte not yet emitted (start of the pending raw segment)
+            uint32_t run_start = 0;    // start of the run of equal bytes the walk is inside
+            for (uint32_t t0 = 0; t0 < lit_count; t0 += 64u) {
+                const uint32_t j = t0 + (uint32_t)lane;
+                const uint32_t b0 = j < lit_count ? e_ld8(lit_out + j) : 0x100u;
+                const uint32_t b1 = j + 1u < lit_count ? e_ld8(lit_out + j + 1u) : 0x200u;
+                const uint64_t E = __ballot(b0 == b1);
+                // run boundaries inside this tile: positions whose byte differs from the next one end a run
+                uint64_t ends = ~E;
+                const uint32_t tile_n = (lit_count - t0 < 64u) ? lit_count - t0 : 64u;
+                if (tile_n < 64u) ends &= (1ull << tile_n) - 1ull;
+                while (ends) {
+                    const uint32_t k = (uint32_t)__builtin_ctzll(ends);
+                    ends &= ends - 1ull;
+                    const uint32_t run_end = t0 + k + 1u;           // exclusive
+                    const uint32_t run = run_end - run_start;
+                    if (run >= 4u) {
+                        // raw segment [seg_start, run_start) first
+                        uint32_t m = run_start - seg_start;
+                        if (pass == 0u) w += m + ((m + 127u) >> 7);
+                        else {
+                            uint32_t s0 = seg_start;
+                            while (m) {
+                                const uint32_t c = m > 128u ? 128u : m;
+                                if (lane == 0) rle_out[w] = (uint8_t)(c - 1u);
+                                for (uint32_t q = lane; q < c; q += 64u) rle_out[w + 1u + q] = lit_out[s0 + q];
+                                w += 1u + c; s0 += c; m -= c;
+                            }
+                        }
+                        const uint32_t full = run / 131u, rem = run - full * 131u;
+                        if (pass == 0u) w += 2u * full + (rem >= 4u ? 2u : (rem ? 1u + rem : 0u));
+                        else {
+                            const uint32_t bv = (uint32_t)__builtin_amdgcn_readlane((int)b0, (int)k);
+                            for (uint32_t q = lane; q < full; q += 64u) { rle_out[w + 2u * q] = (uint8_t)(0x80u | 127u); rle_out[w + 2u * q + 1u] = (uint8_t)bv; }
+                            w += 2u * full;
+                            if (rem >= 4u) {
+                                if (lane == 0) { rle_out[w] = (uint8_t)(0x80u | (rem - 4u)); rle_out[w + 1u] = (uint8_t)bv; }
+                                w += 2u;
+                            } else if (rem) {
+                                if (lane == 0) rle_out[w] = (uint8_t)(rem - 1u);
+                                if ((uint32_t)lane < rem) rle_out[w + 1u + lane] = (uint8_t)bv;
+                                w += 1u + rem;
+                            }
+                        }
+                        seg_start = run_end;
+                    }
+                    run_start = run_end;
+                }
+            }
+            {   // trailing raw segment
+                uint32_t m = lit_count - seg_start;
+                if (pass == 0u) w += m + ((m + 127u) >> 7);
+                else {
+                    uint32_t s0 = seg_start;
+                    while (m) {
+                        const uint32_t c = m > 128u ? 128u : m;
+                        if (lane == 0) rle_out[w] = (uint8_t)(c - 1u);
+                        for (uint32_t q = lane; q < c; q += 64u) rle_out[w + 1u + q] = lit_out[s0 + q];
+                        w += 1u + c; s0 += c; m -= c;
+                    }
+                }
+            }
+            if (pass == 0u) rle_size = w;
+        }
+        if (use_rle) {  // slide the coded section down over the raw one, behind the 4-byte descriptor
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            wave_move_down(slot + 24, rle_out, rle_size, lane);
+        }
+    }
+
+    // ---- assemble: [8 B block header][12 B GLO/GHI header][4 B literal descriptor if RLE][literals]
+    //      GLO: [tokens][offsets][extras][pad]   GHI: [sequence words][extras][pad]
+    const bool off8 = !GHI && max_off <= 256u && max_off != 0u;
+    const uint32_t sz_tok = GHI ? 4u * seq_count : seq_count;
+    const uint32_t sz_off = GHI ? 0u : (off8 ? seq_count : 2u * seq_count);
+    const uint32_t lit_sec = use_rle ? rle_size : lit_count;
+    const uint32_t desc = use_rle ? 4u : 0u;
+    uint32_t behind = sz_tok + sz_off + ext_count;
     const uint32_t pad = behind < 32u ? 32u - behind : 0u;
-    const uint32_t payload = 12u + lit_count + behind + pad;
+    const uint32_t payload = 12u + desc + lit_sec + behind + pad;
     if (overflow || 8u + payload >= n || n < 64u) {
         // RAW block (reference: zxc_encode_block_raw, src/lib/zxc_compress.c:2004-2023)
         for (uint32_t o = 16u * lane; o < n; o += 1024u) {
@@ -284,13 +476,15 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         if (lane == 0) sizes[b] = total;
         return;
     }
-    uint8_t* w = slot + 20 + lit_count;
-    wave_move_down(w, tok_st, seq_count, lane);
-    w += seq_count;
+    uint8_t* w = slot + 20 + desc + lit_sec;
+    wave_move_down(w, tok_st, sz_tok, lane);
+    w += sz_tok;
     if (off8) {
-        for (uint32_t s = lane; s < seq_count; s += 64u) w[s] = off_st[2u * s];
-        __builtin_amdgcn_s_waitcnt(0);
-    } else {
+        for (uint32_t s0 = 0; s0 < seq_count; s0 += 64u) {
+            const uint32_t sq = s0 + (uint32_t)lane;
+            if (sq < seq_count) w[sq] = off_st[2u * sq];
+        }
+    } else if (!GHI) {
         wave_move_down(w, off_st, 2u * seq_count, lane);
     }
     w += sz_off;
@@ -298,11 +492,13 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     w += ext_count;
     if ((uint32_t)lane < pad) w[lane] = 0;
     if (lane == 0) {
-        uint64_t hv = 1ull | ((uint64_t)payload << 24);  // type 1 = GLO
+        uint64_t hv = (GHI ? 2ull : 1ull) | ((uint64_t)payload << 24);  // type 1 = GLO, 2 = GHI
         hv |= (uint64_t)hdr_hash8(hv) << 56;
         __builtin_memcpy(slot, &hv, 8);
-        uint32_t gh[3] = {seq_count, lit_count, (uint32_t)(off8 ? 1u : 0u) << 24};  // enc_lit 0, enc_tok 0, enc_mlen 0, enc_off
+        // n_sequences, n_literals, enc_lit (0 raw / 1 RLE), enc_tok 0, enc_mlen 0, enc_off
+        uint32_t gh[3] = {seq_count, lit_count, (use_rle ? 1u : 0u) | ((uint32_t)(off8 ? 1u : 0u) << 24)};
         __builtin_memcpy(slot + 8, gh, 12);
+        if (use_rle) __builtin_memcpy(slot + 20, &rle_size, 4);
     }
     uint32_t total = 8u + payload;
     if (with_checksum) {
@@ -316,15 +512,31 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     if (lane == 0) sizes[b] = total;
 }
 
-#define ZXC_ENCODE_ENTRY(name, bits)                                                                                   \
-    extern "C" __global__ void __launch_bounds__(64) name(                                                             \
+// Level -> search effort. Reference table (src/lib/zxc_internal.h:965-979): search_depth 3/3/3/3/64/64/128,
+// sufficient_len 16/18/16/18/256/256/256, lazy probes 0/0/1/1(+ip+2)/1(+ip+2)/0/0; levels 1-2 emit GHI and use
+// the 4-byte hash, levels >= 3 GLO and the 5-byte hash. Here every position is inserted, so chains are denser
+// than the CPU's and the deep levels walk fewer links for the same reach; LDS per wave (= occupancy) grows with
+// the level: 8 / 12 / 24 / 24 / 64 / 64 / 64 KiB.
+//   level   head   chain ring   depth   sufficient   lazy   block type
+//     1     2^12      -           1        16          0      GHI
+//     2     2^12     2^11         3        18          0      GHI
+//     3     2^13     2^12         3        16          1      GLO
+//     4     2^13     2^12         6        18          2      GLO
+//     5     2^14     2^14        18       256          2      GLO
+//     6     2^14     2^14        33       256          2      GLO   (optimal parse / PivCo coding: not on the device yet)
+//     7     2^14     2^14        66       256          2      GLO
+#define ZXC_ENCODE_ENTRY(name, hb, cwb, ghi, waves)                                                                    \
+    extern "C" __global__ void __launch_bounds__(64, waves) name(                                                      \
         const uint8_t* __restrict__ src, uint64_t src_size, uint32_t block_size, uint8_t* __restrict__ slots,          \
-        uint32_t slot_stride, uint32_t* __restrict__ sizes, uint32_t n_blocks, uint32_t with_checksum) {               \
-        encode_one_block<bits>(src, src_size, block_size, slots, slot_stride, sizes, n_blocks, with_checksum);         \
+        uint32_t slot_stride, uint32_t* __restrict__ sizes, uint32_t n_blocks, uint32_t with_checksum, uint32_t depth, \
+        uint32_t sufficient, uint32_t lazy) {                                                                          \
+        encode_one_block<hb, cwb, ghi>(src, src_size, block_size, slots, slot_stride, sizes, n_blocks, with_checksum,  \
+                                       depth, sufficient, lazy);                                                       \
     }
-ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_h12, 12u)  // levels 1-2
-ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_h13, 13u)  // levels 3-4
-ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_h14, 14u)  // levels 5-7
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l1, 12u, 0u, true, 5)    // level 1
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l2, 12u, 11u, true, 3)   // level 2
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l34, 13u, 12u, false, 2) // levels 3-4
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l57, 14u, 14u, false, 1) // levels 5-7
 
 // Compaction: block b's bytes [slot, slot+sizes[b]) -> out + offsets[b] (+ optional 4-byte trailer gap).
 extern "C" __global__ void __launch_bounds__(64)

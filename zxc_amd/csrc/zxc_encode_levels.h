@@ -1,0 +1,20 @@
+/* zxc_encode_levels.h — level -> encode kernel entry and search effort (shared by the shim and the test emulator).
+ * Reference parameters: zxc_get_lz77_params, src/lib/zxc_internal.h:965-979; mapping: table in zxc_encode_kernel.hip. */
+#ifndef ZXC_ENCODE_LEVELS_H
+#define ZXC_ENCODE_LEVELS_H
+#include <stdint.h>
+typedef struct { int entry; uint32_t depth, sufficient, lazy; } zxc_enc_level_t;
+static inline zxc_enc_level_t zxc_enc_level(int level) {
+    static const zxc_enc_level_t t[8] = {
+        {0, 1, 16, 0},    /* (fallback = level 1) */
+        {0, 1, 16, 0},    /* 1: head only, GHI */
+        {1, 3, 18, 0},    /* 2: short chain, GHI */
+        {2, 3, 16, 1},    /* 3 */
+        {2, 6, 18, 2},    /* 4 */
+        {3, 18, 256, 2},  /* 5 */
+        {3, 33, 256, 2},  /* 6 */
+        {3, 66, 256, 2},  /* 7 */
+    };
+    return t[level < 1 ? 1 : (level > 7 ? 7 : level)];
+}
+#endif

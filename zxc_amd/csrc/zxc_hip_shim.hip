@@ -25,12 +25,15 @@ extern "C" __global__ void zxc_decode_blocks_dict_kernel(const uint8_t* comp, co
                                                          const uint32_t* order, uint32_t cap_override, const uint8_t* dict,
                                                          uint32_t dict_size, const uint8_t* dict_huf);
 
+#include "zxc_encode_levels.h"
 #define ZXC_ENCODE_DECL(name)                                                                                          \
     extern "C" __global__ void name(const uint8_t* src, uint64_t src_size, uint32_t block_size, uint8_t* slots,        \
-                                    uint32_t slot_stride, uint32_t* sizes, uint32_t n_blocks, uint32_t with_checksum);
-ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_h12)
-ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_h13)
-ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_h14)
+                                    uint32_t slot_stride, uint32_t* sizes, uint32_t n_blocks, uint32_t with_checksum,  \
+                                    uint32_t depth, uint32_t sufficient, uint32_t lazy);
+ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l1)
+ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l2)
+ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l34)
+ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l57)
 extern "C" __global__ void zxc_gather_blocks_kernel(const uint8_t* slots, uint32_t slot_stride, const uint32_t* sizes,
                                                     const uint64_t* offsets, uint8_t* out, uint32_t n_blocks);
 
@@ -223,7 +226,7 @@ uint32_t zxc_mi355x_encode_slot_stride(uint32_t block_size) { return 2u * block_
 
 int zxc_mi355x_encode_blocks_device(const void* d_src, uint64_t src_size, uint32_t block_size, int level,
                                     int with_checksum, void* d_slots, uint32_t* d_sizes, void* stream) {
-    // one match-finding strategy; the level picks the hash-table size = occupancy (zxc_encode_kernel.hip)
+    // the level picks the kernel entry (table geometry = occupancy, GHI / GLO) and the search effort (zxc_encode_levels.h)
     if (src_size == 0) return ZXC_OK;
     if (!d_src || !d_slots || !d_sizes) return ZXC_ERROR_NULL_INPUT;
     if (block_size < (1u << 12) || block_size > (1u << 21) || (block_size & (block_size - 1u))) return ZXC_ERROR_BAD_BLOCK_SIZE;
@@ -231,9 +234,12 @@ int zxc_mi355x_encode_blocks_device(const void* d_src, uint64_t src_size, uint32
     const uint64_t nb64 = (src_size + block_size - 1u) / block_size;
     if (nb64 > 0x7FFFFFFFull) return ZXC_ERROR_BAD_BLOCK_SIZE;
     const uint32_t nb = (uint32_t)nb64;
-    auto kern = level <= 2 ? zxc_encode_blocks_kernel_h12 : level <= 4 ? zxc_encode_blocks_kernel_h13 : zxc_encode_blocks_kernel_h14;
+    const zxc_enc_level_t lp = zxc_enc_level(level);
+    auto kern = lp.entry == 0 ? zxc_encode_blocks_kernel_l1 : lp.entry == 1 ? zxc_encode_blocks_kernel_l2
+              : lp.entry == 2 ? zxc_encode_blocks_kernel_l34 : zxc_encode_blocks_kernel_l57;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_src, src_size, block_size,
-                       (uint8_t*)d_slots, zxc_mi355x_encode_slot_stride(block_size), d_sizes, nb, with_checksum ? 1u : 0u);
+                       (uint8_t*)d_slots, zxc_mi355x_encode_slot_stride(block_size), d_sizes, nb, with_checksum ? 1u : 0u,
+                       lp.depth, lp.sufficient, lp.lazy);
     return hipGetLastError() == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
 }
 
