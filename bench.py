@@ -50,7 +50,7 @@ def tile_bytes(tile, block_size, pool):
     return corpus.synth_silesia_tile(tile, pool=pool)[:n], "synth_silesia tiles (per-tile xor-rotated seed)"
 
 
-def build_rank_corpus(first, last, level, block_size, pool, dev):
+def build_rank_corpus(first, last, level, block_size, pool, dev, checksum=False):
     """Blocks [first, last) of the global corpus, encoded by the unmodified reference (the metric is defined on
     archives written by the reference encoder: "silesia.tar at -3"; untimed input preparation). Only the tiles
     this range touches are generated; compressed blocks and plaintext go straight to HBM, tile by tile, so the
@@ -76,7 +76,7 @@ def build_rank_corpus(first, last, level, block_size, pool, dev):
             data, src = tile_bytes(t, block_size, pool)
             lo, hi = max(first, t * tb) - t * tb, min(last, (t + 1) * tb) - t * tb
             wants.append(torch.frombuffer(bytearray(data[lo * block_size: hi * block_size]), dtype=torch.uint8).to(dev))
-            futs.append((lo, hi, tp.submit(ref.compress, data, level, block_size, True, False)))
+            futs.append((lo, hi, tp.submit(ref.compress, data, level, block_size, True, checksum)))
             del data
         for lo, hi, f in futs:
             comp = f.result()
@@ -365,6 +365,8 @@ def main():
     ap.add_argument("--level", type=int, default=3)
     ap.add_argument("--block-size", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--checksum", action="store_true",
+                    help="archives carry per-block rapidhash trailers and every launch verifies them on the device")
     ap.add_argument("--calib", action="store_true",
                     help="(tools/profile.sh) first launch = a RAW-only archive of known size: 16 B/lane streaming reads "
                          "and writes of known byte counts in the same counter pass, to calibrate FETCH_SIZE / WRITE_SIZE")
@@ -390,7 +392,7 @@ def main():
 
     # ---- workload: this rank's block range of the one corpus
     n_total, first, last = rank_partition(rank, world, args.tiles, bs)
-    d_comp, my_sizes, d_want, hdr, eof, prep, tile0_comp = build_rank_corpus(first, last, args.level, bs, pool, dev)
+    d_comp, my_sizes, d_want, hdr, eof, prep, tile0_comp = build_rank_corpus(first, last, args.level, bs, pool, dev, args.checksum)
     pool.close()
     if world > 1:  # control plane only: every rank learns the whole seek table (4 B per block)
         gathered = [None] * world
@@ -414,7 +416,7 @@ def main():
 
     def step():
         zxc_amd.decode_blocks_device(d_comp.data_ptr(), d_jobs.data_ptr(), n_jobs, d_out.data_ptr(),
-                                     d_status.data_ptr(), bs, False, stream)
+                                     d_status.data_ptr(), bs, args.checksum, stream)
 
     def check(when):
         assert torch.equal(d_status, want_status), f"{when}: block status mismatch on rank {rank}"
@@ -466,7 +468,8 @@ def main():
             cfg = "configs[3] (scaled: --tiles 41 is the full 64 GiB at 8 GPUs)"
         traffic = pmc_traffic(args, args.tiles)
         line = {
-            "metric": f"seekable decode GB/s (level {args.level}, {bs >> 10} KiB independent blocks, HBM-resident in/out)",
+            "metric": f"seekable decode GB/s (level {args.level}, {bs >> 10} KiB independent blocks, HBM-resident in/out"
+                      + (", per-block checksums verified on the device)" if args.checksum else ")"),
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",

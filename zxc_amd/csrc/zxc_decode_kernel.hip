@@ -1042,7 +1042,7 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
     if (enc_tok == 2u) {  // level 7: the token bytes are a PivCo section too
         if (S.n_seq > block_size / 5u + 16u) return E_CORRUPT;
         uint8_t* scratch = scratch_acquire(pool, lane);
-        uint8_t* tokbuf = scratch + 2u * (block_size + 64u);
+        uint8_t* tokbuf = scratch + 2u * (block_size + 64u) + 4096u;  // (behind the directory area of block_size + 64 + 4096 bytes)
         const int rc = pivco_decode(S.tok, tok_comp, tokbuf, S.n_seq, scratch + block_size + 64u,
                                     reinterpret_cast<PivLds&>(L), lane, nullptr, dbg);
         if (rc != 0) return rc;

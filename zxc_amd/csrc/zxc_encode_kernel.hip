@@ -119,18 +119,6 @@ __device__ __forceinline__ uint32_t prefix16(uint64_t a_lo, uint64_t a_hi, const
     if (xh) return 8u + (uint32_t)(__builtin_ctzll(xh) >> 3);
     return 16u;
 }
-// a candidate whose first 16 bytes match: extend 8 bytes at a time (src/lib/zxc_compress.c:270-330), up to the block end
-__device__ __forceinline__ uint32_t extend_match(const uint8_t* in, uint32_t i, uint32_t c, uint32_t n) {
-    uint32_t len = 16;
-    while (i + len + 8u <= n) {
-        const uint64_t y = e_ld64(in + i + len) ^ e_ld64(in + c + len);
-        if (y) return len + (uint32_t)(__builtin_ctzll(y) >> 3);
-        len += 8u;
-    }
-    while (i + len < n && in[i + len] == in[c + len]) len++;
-    return len;
-}
-
 // Slot layout while encoding (stride = 2*block_size + 512 bytes per block):
 //   [0,8) block header | [8,20) GLO/GHI header | literals ... | ... staging from block_size + 64: tokens (GLO: 1 B,
 //   GHI: 4-byte words), offsets (GLO), extras
@@ -219,9 +207,31 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             if (db) cb = e_ld128(in + i - db);
             if (dc) cc = e_ld128(in + i - dc);
             uint32_t ma = da ? prefix16(v, vh, ca) : 0u, mb = db ? prefix16(v, vh, cb) : 0u, mc = dc ? prefix16(v, vh, cc) : 0u;
-            if (ma == 16u) ma = extend_match(in, i, i - da, n);
-            if (mb == 16u && ma < sufficient) mb = extend_match(in, i, i - db, n);
-            if (mc == 16u && ma < sufficient && mb < sufficient) mc = extend_match(in, i, i - dc, n);
+            // candidates whose first 16 bytes match are extended TOGETHER, 16 bytes per step: one request for my own
+            // bytes and one per live candidate, all in flight at once, so a step costs one memory round trip however
+            // many candidates are still running (the reference extends them one after the other, 8 bytes at a time)
+            {
+                bool la = ma == 16u, lb = mb == 16u, lc = mc == 16u;
+                uint32_t L = 16u;
+                while (la | lb | lc) {
+                    if (i + L + 16u > n) {  // block tail: finish bytewise
+                        if (la) { ma = L; while (i + ma < n && in[i + ma] == in[i - da + ma]) ma++; la = false; }
+                        if (lb) { mb = L; while (i + mb < n && in[i + mb] == in[i - db + mb]) mb++; lb = false; }
+                        if (lc) { mc = L; while (i + mc < n && in[i + mc] == in[i - dc + mc]) mc++; lc = false; }
+                        break;
+                    }
+                    const v4u own = e_ld128(in + i + L);
+                    v4u xa = own, xb = own, xc = own;
+                    if (la) xa = e_ld128(in + i - da + L);
+                    if (lb) xb = e_ld128(in + i - db + L);
+                    if (lc) xc = e_ld128(in + i - dc + L);
+                    const uint64_t olo = (uint64_t)own.x | ((uint64_t)own.y << 32), ohi = (uint64_t)own.z | ((uint64_t)own.w << 32);
+                    if (la) { const uint32_t m = prefix16(olo, ohi, xa); if (m < 16u) { ma = L + m; la = false; } }
+                    if (lb) { const uint32_t m = prefix16(olo, ohi, xb); if (m < 16u) { mb = L + m; lb = false; } }
+                    if (lc) { const uint32_t m = prefix16(olo, ohi, xc); if (m < 16u) { mc = L + m; lc = false; } }
+                    L += 16u;
+                }
+            }
             if (ma > len) { len = ma; dist = da; }   // (first = nearest wins ties: smaller offsets, cheaper tokens)
             if (mb > len) { len = mb; dist = db; }
             if (mc > len) { len = mc; dist = dc; }
