@@ -202,17 +202,24 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
                 dc = next(db, tried + 2u < depth);
                 dn = next(dc, tried + 3u < depth);
             }
-            v4u ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0}, cc = {0, 0, 0, 0};
-            if (da) ca = e_ld128(in + i - da);
-            if (db) cb = e_ld128(in + i - db);
-            if (dc) cc = e_ld128(in + i - dc);
+            // 32 bytes of every candidate (and my own second 16) are requested together: most matches end inside
+            // them, so a round costs ONE memory round trip; only longer ones enter the extension loop below
+            v4u ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0}, cc = {0, 0, 0, 0}, ca2 = ca, cb2 = ca, cc2 = ca, own2 = ca;
+            if (da) { ca = e_ld128(in + i - da); ca2 = e_ld128(in + i - da + 16u); }
+            if (db) { cb = e_ld128(in + i - db); cb2 = e_ld128(in + i - db + 16u); }
+            if (dc) { cc = e_ld128(in + i - dc); cc2 = e_ld128(in + i - dc + 16u); }
+            if (da) own2 = e_ld128(in + i + 16u);  // (may reach up to 16 bytes past the block: lengths are clamped to it below)
+            const uint64_t o2lo = (uint64_t)own2.x | ((uint64_t)own2.y << 32), o2hi = (uint64_t)own2.z | ((uint64_t)own2.w << 32);
             uint32_t ma = da ? prefix16(v, vh, ca) : 0u, mb = db ? prefix16(v, vh, cb) : 0u, mc = dc ? prefix16(v, vh, cc) : 0u;
-            // candidates whose first 16 bytes match are extended TOGETHER, 16 bytes per step: one request for my own
+            if (ma == 16u) ma += prefix16(o2lo, o2hi, ca2);
+            if (mb == 16u) mb += prefix16(o2lo, o2hi, cb2);
+            if (mc == 16u) mc += prefix16(o2lo, o2hi, cc2);
+            // candidates still equal after 32 bytes are extended TOGETHER, 16 bytes per step: one request for my own
             // bytes and one per live candidate, all in flight at once, so a step costs one memory round trip however
             // many candidates are still running (the reference extends them one after the other, 8 bytes at a time)
             {
-                bool la = ma == 16u, lb = mb == 16u, lc = mc == 16u;
-                uint32_t L = 16u;
+                bool la = ma == 32u, lb = mb == 32u, lc = mc == 32u;
+                uint32_t L = 32u;
                 while (la | lb | lc) {
                     if (i + L + 16u > n) {  // block tail: finish bytewise
                         if (la) { ma = L; while (i + ma < n && in[i + ma] == in[i - da + ma]) ma++; la = false; }
@@ -231,6 +238,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
                     if (lc) { const uint32_t m = prefix16(olo, ohi, xc); if (m < 16u) { mc = L + m; lc = false; } }
                     L += 16u;
                 }
+                // (the tail path above clamps at n; a 16 / 32-byte prefix that straddles the block end is clamped below)
             }
             if (ma > len) { len = ma; dist = da; }   // (first = nearest wins ties: smaller offsets, cheaper tokens)
             if (mb > len) { len = mb; dist = db; }
@@ -241,8 +249,10 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         if (len > n - i) len = n - i;
         if (len < 5u) { len = 0; dist = 0; }
         // backward extension available at this position: equal bytes just before both sides (<= 16)
+        // (with every position inserted, position i-1 finds the same candidate itself, so growing backwards changes
+        // next to nothing — identical archive sizes at levels 1-4 in tests/wave_emu — and is kept for the deep levels)
         uint32_t bk = 0;
-        if (len && i >= 16u && i - dist >= 16u) {
+        if (depth > 8u && len && i >= 16u && i - dist >= 16u) {
             const uint64_t y = e_ld64(in + i - 8u) ^ e_ld64(in + i - dist - 8u);
             const uint64_t y2 = e_ld64(in + i - 16u) ^ e_ld64(in + i - dist - 16u);
             bk = y ? (uint32_t)(__builtin_clzll(y) >> 3) : (y2 ? 8u + (uint32_t)(__builtin_clzll(y2) >> 3) : 16u);
