@@ -383,7 +383,14 @@ __device__ __forceinline__ uint32_t parse_varints(const uint8_t* ext, uint32_t e
     return kbad;
 }
 
+#ifndef PIV_TOPDOWN
+#define PIV_TOPDOWN 0   // 1: experimental top-down (wavelet-tree) section decoder, zxc_pivco_topdown.inc (measured slower: DESIGN.md)
+#endif
+#if PIV_TOPDOWN
+#include "zxc_pivco_topdown.inc"
+#else
 #include "zxc_pivco.inc"
+#endif
 #include "zxc_rapidhash.inc"
 
 // ------------------------------------------------------------------ block decode
