@@ -4,8 +4,10 @@ reported in DESIGN.md next to the HBM-resident number, never as the bench value.
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import zxc_amd, bench
-data, comp, prep = bench.build_workload(64 << 20, 3, 65536)
+import zxc_amd, oracle_py
+from zxc_amd import corpus
+data = corpus.synth_silesia(64 << 20, seed=0)
+comp = oracle_py.Ref().compress(data, 3, 65536, True, False)
 zxc_amd.decompress(comp)  # warm-up (context, scratch)
 best = 1e9
 for _ in range(5):
