@@ -17,7 +17,7 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
     // padded private copies: the kernels read (never use) a few bytes past the ends, as they may in device buffers
     std::vector<uint8_t> c(comp_bytes + 8192, 0xEE), o(out_bytes + 8192, 0xDD);
     memcpy(c.data() + 4096, comp, comp_bytes);
-    const uint32_t stride = (2u * (block_size + 64u) + 4096u + block_size / 5u + 16u + 64u + 255u) & ~255u;
+    const uint32_t stride = (2u * (block_size + 64u) + block_size / 5u + 16u + 64u + 255u) & ~255u;
     const uint32_t n_slots = 4;
     std::vector<uint8_t> scratch((size_t)n_slots * stride + 4096, 0xCC);
     std::vector<uint32_t> busy(8192, 0);

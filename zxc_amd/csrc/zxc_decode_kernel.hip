@@ -50,7 +50,7 @@ typedef v4u __attribute__((aligned(1))) v4u_unaligned;
 #define REDIRECT_PASSES 2   // chained containment levels resolved before round 0 (A/B: 0: -6 %, 1: -2 %, 2: best, 3: -1 %)
 #endif
 #ifndef SPARSE_MAX
-#define SPARSE_MAX 4   // at most this many unfinished sequences after a round: finish them one by one
+#define SPARSE_MAX 8   // at most this many unfinished sequences after a round: finish them one by one (A/B: 2: -0.3 %, 4: 0, 8: +1 %)
 #endif
 #ifndef TILE_MAX
 // A batch never spans more output than this: the ring must hold the batch, the not yet flushed tail of the
@@ -58,7 +58,8 @@ typedef v4u __attribute__((aligned(1))) v4u_unaligned;
 #define TILE_MAX 3584u
 #endif
 #ifndef LIT_MED
-#define LIT_MED 48u      // literal runs up to this long are put lane-per-sequence (16-byte grid steps), longer ones by the whole wave
+#define LIT_MED 128u     // literal runs up to this long are put lane-per-sequence (16-byte grid steps), longer ones by the whole wave
+                         // (A/B on the bench corpus: 32: -9 %, 48: 0, 96: +8 %, 128 / 160 / 224: +10 %)
 #endif
 #ifndef MATCH_MED
 #define MATCH_MED 128u   // matches up to this long are copied lane-per-sequence (16-byte grid steps)
@@ -383,11 +384,10 @@ __device__ __forceinline__ uint32_t parse_varints(const uint8_t* ext, uint32_t e
     return kbad;
 }
 
-#ifndef PIV_TOPDOWN
-#define PIV_TOPDOWN 0   // 1: experimental top-down (wavelet-tree) section decoder, zxc_pivco_topdown.inc (measured slower: DESIGN.md)
-#endif
-#if PIV_TOPDOWN
-#include "zxc_pivco_topdown.inc"
+// (Two other section decoders were built and measured this round — a top-down wavelet-tree walk and an LDS-tiled
+// bottom-up merge, tools/experiments/zxc_pivco_*.inc — both slower on the GPU than this one: DESIGN.md §3.)
+#ifdef PIV_VARIANT_FILE
+#include PIV_VARIANT_FILE
 #else
 #include "zxc_pivco.inc"
 #endif
@@ -1049,7 +1049,7 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
     if (enc_tok == 2u) {  // level 7: the token bytes are a PivCo section too
         if (S.n_seq > block_size / 5u + 16u) return E_CORRUPT;
         uint8_t* scratch = scratch_acquire(pool, lane);
-        uint8_t* tokbuf = scratch + 2u * (block_size + 64u) + 4096u;  // (behind the directory area of block_size + 64 + 4096 bytes)
+        uint8_t* tokbuf = scratch + 2u * (block_size + 64u);
         const int rc = pivco_decode(S.tok, tok_comp, tokbuf, S.n_seq, scratch + block_size + 64u,
                                     reinterpret_cast<PivLds&>(L), lane, nullptr, dbg);
         if (rc != 0) return rc;

@@ -111,14 +111,15 @@ __device__ __forceinline__ void wave_move_down(uint8_t* dst, const uint8_t* src,
     __builtin_amdgcn_wave_barrier();
 }
 
-// common prefix (bytes, 0..16) of two 16-byte groups
+// common prefix (bytes, 0..16) of two 16-byte groups (branch-free: the lanes of a wave all take different ways)
 __device__ __forceinline__ uint32_t prefix16(uint64_t a_lo, uint64_t a_hi, const v4u c) {
     const uint64_t x = a_lo ^ ((uint64_t)c.x | ((uint64_t)c.y << 32));
     const uint64_t xh = a_hi ^ ((uint64_t)c.z | ((uint64_t)c.w << 32));
-    if (x) return (uint32_t)(__builtin_ctzll(x) >> 3);
-    if (xh) return 8u + (uint32_t)(__builtin_ctzll(xh) >> 3);
-    return 16u;
+    const uint32_t lo = x ? (uint32_t)__builtin_ctzll(x) : 64u;
+    const uint32_t hi = xh ? (uint32_t)__builtin_ctzll(xh) : 64u;
+    return (x ? lo : 64u + hi) >> 3;
 }
+
 // Slot layout while encoding (stride = 2*block_size + 512 bytes per block):
 //   [0,8) block header | [8,20) GLO/GHI header | literals ... | ... staging from block_size + 64: tokens (GLO: 1 B,
 //   GHI: 4-byte words), offsets (GLO), extras
@@ -204,11 +205,13 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             }
             // 32 bytes of every candidate (and my own second 16) are requested together: most matches end inside
             // them, so a round costs ONE memory round trip; only longer ones enter the extension loop below
-            v4u ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0}, cc = {0, 0, 0, 0}, ca2 = ca, cb2 = ca, cc2 = ca, own2 = ca;
-            if (da) { ca = e_ld128(in + i - da); ca2 = e_ld128(in + i - da + 16u); }
-            if (db) { cb = e_ld128(in + i - db); cb2 = e_ld128(in + i - db + 16u); }
-            if (dc) { cc = e_ld128(in + i - dc); cc2 = e_ld128(in + i - dc + 16u); }
-            if (da) own2 = e_ld128(in + i + 16u);  // (may reach up to 16 bytes past the block: lengths are clamped to it below)
+            // (requested by every lane — a lane without that candidate re-reads its own position — so that the seven
+            // loads are issued back to back and waited for once: a load under a condition is waited for on the spot)
+            const uint8_t* pme = can ? in + i : in;
+            const v4u ca = e_ld128(pme - da), ca2 = e_ld128(pme - da + 16u);
+            const v4u cb = e_ld128(pme - db), cb2 = e_ld128(pme - db + 16u);
+            const v4u cc = e_ld128(pme - dc), cc2 = e_ld128(pme - dc + 16u);
+            const v4u own2 = e_ld128(pme + 16u);  // (may reach up to 16 bytes past the block: lengths are clamped to it below)
             const uint64_t o2lo = (uint64_t)own2.x | ((uint64_t)own2.y << 32), o2hi = (uint64_t)own2.z | ((uint64_t)own2.w << 32);
             uint32_t ma = da ? prefix16(v, vh, ca) : 0u, mb = db ? prefix16(v, vh, cb) : 0u, mc = dc ? prefix16(v, vh, cc) : 0u;
             if (ma == 16u) ma += prefix16(o2lo, o2hi, ca2);

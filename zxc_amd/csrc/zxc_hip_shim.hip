@@ -131,8 +131,8 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
         if (nb > 32) nb = 32;
         g_dev[dev].wg_per_cu = nb;
     }
-    // scratch slot: [expanded literals | PivCo rank directory (block_size + 64 + 4096) | decoded tokens]
-    const uint32_t stride = (2u * (block_size + 64u) + 4096u + block_size / 5u + 16u + 64u + 255u) & ~255u;
+    // scratch slot: [expanded literals | PivCo ping-pong | decoded tokens]
+    const uint32_t stride = (2u * (block_size + 64u) + block_size / 5u + 16u + 64u + 255u) & ~255u;
     // Only blocks with an RLE / PivCo section take a slot, waiters spin and holders never wait, so
     // the pool may be smaller than the resident workgroup count: cap it at 1 GiB of scratch.
     const uint32_t max_slots = (uint32_t)g_dev[dev].cus * (uint32_t)g_dev[dev].wg_per_cu;  // <= 8192
