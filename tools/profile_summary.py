@@ -3,9 +3,10 @@
 Usage: python tools/profile_summary.py r1"""
 import collections, csv, json, os, shutil, sys
 tag = sys.argv[1]
+KERNEL_ARG = sys.argv[2] if len(sys.argv) > 2 else None  # e.g. zxc_encode_blocks_kernel_l34 for the encode bench
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out"); P = os.path.join(ROOT, "profiles"); os.makedirs(P, exist_ok=True)
-KERNEL = "zxc_decode_blocks_kernel"
+KERNEL = KERNEL_ARG or "zxc_decode_blocks_kernel"
 
 CALIB = {}  # counter -> value of the calibration launch (bench.py --calib: the first decode-kernel dispatch)
 
@@ -15,9 +16,10 @@ def counters(path):
     for r in csv.DictReader(open(path)):
         if KERNEL in r["Kernel_Name"]:
             per[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
-    for c, d in per.items():  # bench.py --calib: first launch = RAW-only archive of known size, not a workload launch
-        first = min(d)
-        CALIB[c] = d.pop(first)
+    if KERNEL_ARG is None:
+        for c, d in per.items():  # bench.py --calib: first launch = RAW-only archive of known size, not a workload launch
+            first = min(d)
+            CALIB[c] = d.pop(first)
     return {c: sum(d.values()) / len(d) for c, d in per.items()}, {c: len(d) for c, d in per.items()}
 
 out = {"kernel": KERNEL, "tag": tag}
@@ -32,19 +34,21 @@ kt = os.path.join(G, f"{tag}_kt", "kt_kernel_trace.csv")
 if os.path.exists(kt):
     d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
                for r in csv.DictReader(open(kt)) if KERNEL in r["Kernel_Name"])
-    timed = [x[1] for x in d[3:8]]
+    timed = [x[1] for x in (d[3:8] if KERNEL_ARG is None else d[1:6])]  # encode bench: 1 warm-up, 5 timed
     if timed:
         out["kernel_trace"]["steady_state_avg_ns"] = sum(timed) / len(timed)
         out["kernel_trace"]["steady_state_launches"] = len(timed)
-        out["kernel_trace"]["calibration_launch_ns"] = d[0][1]
+        if KERNEL_ARG is None:
+            out["kernel_trace"]["calibration_launch_ns"] = d[0][1]
 log = os.path.join(G, f"{tag}_kt.log")
 if os.path.exists(log):
     for line in open(log):
         if line.startswith("{") and '"metric"' in line:
             b = json.loads(line)
             out["bench_line"] = {k: b[k] for k in ("value", "ms_per_step", "config", "roofline", "calibration") if k in b}
-            out["workload"] = {"tiles": b["config"]["prep"]["tiles"], "level": int(b["metric"].split("level ")[1].split(",")[0]),
-                               "block_size": b["config"]["decoded_bytes_per_gpu"] // b["config"]["blocks_per_gpu"]}
+            if "prep" in b["config"]:
+                out["workload"] = {"tiles": b["config"]["prep"]["tiles"], "level": int(b["metric"].split("level ")[1].split(",")[0]),
+                                   "block_size": b["config"]["decoded_bytes_per_gpu"] // b["config"]["blocks_per_gpu"]}
 pm = {}
 for sub, f in (("fetch", "f"), ("write", "w"), ("sq", "s")):
     p = os.path.join(G, f"{tag}_{sub}", f"{f}_counter_collection.csv")

@@ -64,6 +64,9 @@ typedef v4u __attribute__((aligned(1))) v4u_unaligned;
 #ifndef MATCH_MED
 #define MATCH_MED 128u   // matches up to this long are copied lane-per-sequence (16-byte grid steps)
 #endif
+#ifndef LIT_LOOP2
+#define LIT_LOOP2 1      // literal groups beyond the third: two per step, requested unconditionally (0: one conditional load per step)
+#endif
 #ifndef FAR_EARLY
 #define FAR_EARLY 0      // 1: far-source groups requested unconditionally, before the literal wait (A/B)
 #endif
@@ -716,6 +719,20 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                     const uint32_t t = (lshort && le > 32u) ? (le - 32u < 16u ? le - 32u : 16u) : 0u;
                     ring_or_group(L, lg + 32u, group_keep_first(L, lv2, t));
                 }
+#if LIT_LOOP2
+#pragma unroll 1
+                for (uint32_t go = 48u; go < LIT_MED + 4u; go += 32u) {  // two groups per step, both requested by every lane
+                    const bool actA = lshort && le > go, actB = lshort && le > go + 16u;
+                    if (__ballot(actA) == 0ull) break;
+                    // (a load under a condition is waited for on the spot: idle lanes re-read the start of the literal stream)
+                    const v4u lvA = ld128(actA ? lsrc + go : S.lit);
+                    const v4u lvB = ld128(actB ? lsrc + go + 16u : S.lit);
+                    const uint32_t tA = actA ? (le - go < 16u ? le - go : 16u) : 0u;
+                    const uint32_t tB = actB ? (le - go - 16u < 16u ? le - go - 16u : 16u) : 0u;
+                    ring_or_group(L, lg + go, group_keep_first(L, lvA, tA));
+                    ring_or_group(L, lg + go + 16u, group_keep_first(L, lvB, tB));
+                }
+#else
 #pragma unroll 1
                 for (uint32_t go = 48u; go < LIT_MED + 4u; go += 16u) {
                     const bool act = lshort && le > go;
@@ -725,6 +742,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                     const uint32_t t = act ? (le - go < 16u ? le - go : 16u) : 0u;
                     ring_or_group(L, lg + go, group_keep_first(L, lv, t));
                 }
+#endif
                 PH(7);  // (experiment builds: slot 7 = literal groups, slot 1 = long literals)
                 uint64_t lm = __ballot(mine && ll > LIT_MED);
                 while (lm) {
