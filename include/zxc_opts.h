@@ -14,7 +14,7 @@ typedef void (*zxc_progress_callback_t)(uint64_t bytes_processed, uint64_t bytes
 
 typedef struct {
     int n_threads;        /* ignored: parallelism is the GPU's */
-    int level;            /* 1..7, 0 = default (3) */
+    int level;            /* 1..7, 0 = default (3); device encoder effort per level: INTEGRATION.md / zxc_encode_levels.h */
     size_t block_size;    /* power of two in [4 KiB, 2 MiB], 0 = 512 KiB */
     int checksum_enabled;
     int seekable;

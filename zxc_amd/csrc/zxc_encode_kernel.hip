@@ -51,6 +51,13 @@ __device__ __forceinline__ uint64_t e_ld64(const uint8_t* p) { uint64_t v; __bui
 __device__ __forceinline__ v4u e_ld128(const uint8_t* p) { v4u v; __builtin_memcpy(&v, p, 16); return v; }
 __device__ __forceinline__ uint32_t e_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// LDS traffic between the lanes of the ONE wave of a workgroup: order it (lgkmcnt only). __syncthreads() would also wait
+// for every global store and load in flight (vmcnt(0)), i.e. for the token / literal stores of the previous chunk.
+__device__ __forceinline__ void enc_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ uint32_t e_scan_add(uint32_t v) {  // wave inclusive prefix sum (DPP)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
@@ -153,7 +160,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
 
     for (uint32_t i = lane; i < HSIZE / 2u; i += 64u) ((uint32_t*)ht)[i] = 0u;
     if (CWB) for (uint32_t i = lane; i < CW / 2u; i += 64u) ((uint32_t*)chain)[i] = 0u;
-    __syncthreads();
+    enc_lds_fence();
 
     uint32_t seq_count = 0, lit_count = 0, ext_count = 0, max_off = 0;
     uint32_t pos = 0;     // next position the parse will look at
@@ -262,21 +269,21 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         }
         // ---- 3. publish this chunk's positions: lookups above saw only earlier chunks
         __builtin_amdgcn_wave_barrier();
-        __syncthreads();
+        enc_lds_fence();
         if (can && CWB) chain[i & CWM] = (uint16_t)d0;
         // head: the highest position of a bucket must win whatever order the hardware applies colliding stores in
         {
             bool want = can;
             for (;;) {
                 if (want) ht[h] = (uint16_t)i;
-                __syncthreads();
+                enc_lds_fence();
                 const uint32_t behind = can ? ((i - (uint32_t)ht[h]) & 0xFFFFu) : 0u;  // 0: mine is in; 1..63: an earlier lane's
                 want = behind != 0u && behind < 64u;
                 if (__ballot(want) == 0ull) break;
-                __syncthreads();
+                enc_lds_fence();
             }
         }
-        __syncthreads();
+        enc_lds_fence();
 
         // ---- 4. scalar parse of the chunk: greedy + the level's lazy probes + backward extension
         uint64_t sel = 0;
