@@ -83,6 +83,14 @@ ZXC_EXPORT uint32_t zxc_mi355x_encode_slot_stride(uint32_t block_size);
 ZXC_EXPORT int zxc_mi355x_encode_blocks_device(const void* d_src, uint64_t src_size, uint32_t block_size,
                                                int level, int with_checksum, void* d_slots,
                                                uint32_t* d_sizes, void* stream);
+/* Same with a dictionary (reference: opts.dict of zxc_compress, src/lib/zxc_dispatch.c:700-733, and the [dict | block]
+ * buffer of zxc_compress_block :1688-1697): every block's tables are seeded with d_dict[0..dict_size), matches may reach
+ * into it. d_work is scratch of zxc_mi355x_encode_dict_work_size() bytes (one [dict | block] image per block). */
+ZXC_EXPORT uint64_t zxc_mi355x_encode_dict_work_size(uint64_t src_size, uint32_t block_size, uint32_t dict_size);
+ZXC_EXPORT int zxc_mi355x_encode_blocks_dict_device(const void* d_src, uint64_t src_size, uint32_t block_size,
+                                                    int level, int with_checksum, const void* d_dict,
+                                                    uint32_t dict_size, void* d_work, void* d_slots,
+                                                    uint32_t* d_sizes, void* stream);
 /* Compaction: block i's d_sizes[i] bytes go to d_out + d_offsets[i] (prefix sums computed by the
  * caller, like seek_comp[] in src/lib/zxc_dispatch.c:761-776). */
 ZXC_EXPORT int zxc_mi355x_gather_blocks_device(const void* d_slots, uint32_t block_size,

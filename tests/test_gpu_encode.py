@@ -6,7 +6,7 @@ import random
 
 import pytest
 
-from conftest import read
+from conftest import GOLDEN, load_dict, read
 
 pytestmark = pytest.mark.gpu
 
@@ -100,3 +100,47 @@ def test_large_corpus_and_ratio(gpu, ref):
             print(f"\n{what} level {level}: GPU encoder {len(comp)} B vs reference {len(cpu)} B "
                   f"(ratio {len(data)/len(comp):.3f} vs {len(data)/len(cpu):.3f})")
             assert len(comp) <= 1.03 * len(cpu), (what, level, len(comp), len(cpu))
+
+
+def test_dictionary_compression(gpu, oracle, ref):
+    """zxc_compress / zxc_compress_block with opts.dict (reference src/lib/zxc_dispatch.c:700-733, :1688-1697): the header
+    carries HAS_DICTIONARY + the dict id, blocks reference the dictionary; decoded by the unmodified reference with the
+    dictionary (DICT_REQUIRED without it, DICT_MISMATCH with another one) and by our decoder."""
+    import ctypes as C
+    import os
+    import oracle_py
+    d, dh = load_dict(os.path.join(GOLDEN, "conformance", "valid", "dict_http.zxd"))
+    data = read("conformance/valid/dict_http.expected")[:30000] * 3
+    R = oracle_py.bind_block_api(ref.lib)
+    for level, bs in ((3, 4096), (1, 8192), (5, 65536)):
+        for huf in (dh, None):
+            comp = gpu.compress(data, level, bs, True, False, dict_=d, dict_huf=huf)
+            plain = gpu.compress(data, level, bs, True, False)
+            assert R.zxc_get_dict_id(comp, len(comp)) != 0 and R.zxc_get_dict_id(plain, len(plain)) == 0
+            o = oracle_py.DecompressOpts()
+            keep = (C.create_string_buffer(d, len(d)), C.create_string_buffer(huf, 128) if huf else None)
+            o.dict, o.dict_size = C.cast(keep[0], C.c_void_p), len(d)
+            o.dict_huf = C.cast(keep[1], C.c_void_p) if huf else None
+            out = C.create_string_buffer(len(data))
+            assert ref.lib.zxc_decompress(comp, len(comp), out, len(data), C.byref(o)) == len(data) and out.raw == data
+            assert ref.decompress(comp, len(data))[0] == -15
+            assert gpu.decompress(comp, dict_=d, dict_huf=huf) == data
+            assert gpu.decompress(comp, raise_on_error=False)[0] == -15
+            assert gpu.decompress(comp, raise_on_error=False, dict_=d[:-1] + b"?", dict_huf=huf)[0] == -16
+            if bs <= 8192:
+                assert len(comp) < 0.9 * len(plain), (level, bs, len(comp), len(plain))
+    # Block API with a dictionary, both directions against the reference
+    P = oracle_py.BlockApi(C.CDLL(gpu.lib_path()))
+    RB = oracle_py.BlockApi(ref.lib)
+    blk_data = data[:4096]
+    for W, V in ((P, RB), (RB, P)):
+        o = oracle_py.CompressOpts(level=3)
+        keep = C.create_string_buffer(d, len(d))
+        o.dict, o.dict_size = C.cast(keep, C.c_void_p), len(d)
+        cap = int(W.L.zxc_compress_block_bound(len(blk_data)))
+        dst = C.create_string_buffer(cap)
+        rc = W.L.zxc_compress_block(W.c, blk_data, len(blk_data), dst, cap, C.byref(o))
+        assert rc > 0
+        assert V.decompress_block(dst.raw[:rc], len(blk_data) + 2112, dict_=d) == (len(blk_data), blk_data)
+    P.close()
+    RB.close()

@@ -141,3 +141,28 @@ def test_encoder_rle_literals_on_emulator(emu, ref, oracle):
     comp = _enc_roundtrip(emu, ref, oracle, bytes(b), 3)
     assert comp[16] == 1 and comp[16 + 8 + 8] == 1, "GLO block with enc_lit = 1 expected"
     assert len(comp) <= 1.10 * len(ref.compress(bytes(b), 3, 65536, True, False))
+
+
+def test_encoder_dictionary_on_emulator(emu, ref, oracle):
+    """Dictionary compression (reference opts.dict, zxc_lz_seed_dict): the dictionary seeds every block's tables and
+    matches reach into it. Small HTTP-like blocks against the conformance HTTP dictionary: the archive decodes with the
+    unmodified reference + dictionary, is rejected without it, and is much smaller than without a dictionary."""
+    import ctypes as C
+    import oracle_py
+    d, dh = load_dict(os.path.join(GOLDEN, "conformance", "valid", "dict_http.zxd"))
+    name = sorted(f for f in os.listdir(os.path.join(GOLDEN, "conformance", "valid")) if f.startswith("dict_http") and f.endswith(".zxc"))[0]
+    dict_id = int.from_bytes(read(f"conformance/valid/{name}")[7:11], "little")
+    data = read(f"conformance/valid/{name[:-4]}.expected")[:20000] * 2
+    for level, bs in ((3, 4096), (1, 4096), (5, 65536)):
+        comp = emu.encode(data, level, bs, dict_=d, dict_id=dict_id)
+        plain = emu.encode(data, level, bs)
+        o = oracle_py.DecompressOpts()
+        keep = (C.create_string_buffer(d, len(d)), C.create_string_buffer(dh, 128))
+        o.dict, o.dict_size, o.dict_huf = C.cast(keep[0], C.c_void_p), len(d), C.cast(keep[1], C.c_void_p)
+        out = C.create_string_buffer(len(data))
+        assert ref.lib.zxc_decompress(comp, len(comp), out, len(data), C.byref(o)) == len(data) and out.raw == data, (level, bs)
+        assert ref.decompress(comp, len(data))[0] == -15  # DICT_REQUIRED
+        rc, got = oracle.decompress(comp, len(data), dict_=d, dict_huf=dh)
+        assert rc == len(data) and got == data
+        if bs == 4096:
+            assert len(comp) < 0.9 * len(plain), (level, len(comp), len(plain))

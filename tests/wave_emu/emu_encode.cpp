@@ -19,13 +19,13 @@ extern char __start_emu_lds[], __stop_emu_lds[];
 // level -> kernel entry + search effort, exactly as zxc_mi355x_encode_blocks_device (zxc_hip_shim.hip) picks them
 #include "zxc_encode_levels.h"
 static void zxc_encode_dispatch(int level, const uint8_t* src, uint64_t src_size, uint32_t block_size, uint8_t* slots,
-                                uint32_t stride, uint32_t* sizes, uint32_t nb, uint32_t ck) {
+                                uint32_t stride, uint32_t* sizes, uint32_t nb, uint32_t ck, uint32_t dict_size) {
     const zxc_enc_level_t p = zxc_enc_level(level);
     switch (p.entry) {
-        case 0: zxc_encode_blocks_kernel_l1(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy); break;
-        case 1: zxc_encode_blocks_kernel_l2(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy); break;
-        case 2: zxc_encode_blocks_kernel_l34(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy); break;
-        default: zxc_encode_blocks_kernel_l57(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy); break;
+        case 0: zxc_encode_blocks_kernel_l1(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size); break;
+        case 1: zxc_encode_blocks_kernel_l2(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size); break;
+        case 2: zxc_encode_blocks_kernel_l34(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size); break;
+        default: zxc_encode_blocks_kernel_l57(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size); break;
     }
 }
 
@@ -35,15 +35,22 @@ uint32_t emu_encode_slot_stride(uint32_t block_size) { return 2u * block_size + 
 // slots: n_blocks * stride bytes, sizes: n_blocks entries (same contract as zxc_mi355x_encode_blocks_device)
 extern "C" __attribute__((visibility("default")))
 int emu_encode_blocks(const uint8_t* src, uint64_t src_size, uint32_t block_size, int level, int with_checksum,
-                      uint8_t* slots, uint32_t* sizes) {
+                      uint8_t* slots, uint32_t* sizes, const uint8_t* dict, uint32_t dict_size) {
     const uint32_t nb = (uint32_t)((src_size + block_size - 1) / block_size);
     const uint32_t stride = emu_encode_slot_stride(block_size);
-    std::vector<uint8_t> s(src_size + 8192, 0xEE);
+    std::vector<uint8_t> s(src_size + 8192, 0xEE), work;
     memcpy(s.data() + 4096, src, src_size);
+    const uint8_t* in = s.data() + 4096;
+    if (dict_size) {  // [dict | block] images, as zxc_mi355x_encode_blocks_dict_device prepares them
+        work.assign((size_t)nb * ((size_t)block_size + dict_size) + 8192, 0xEE);
+        for (uint32_t b = 0; b < nb; b++)
+            emu::run_wave([&] { zxc_prepend_dict_kernel(s.data() + 4096, src_size, block_size, dict, dict_size, work.data() + 4096, nb); }, b, nb, 64);
+        in = work.data() + 4096;
+    }
     for (uint32_t b = 0; b < nb; b++) {
         memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));
         emu::run_wave([&] {
-            zxc_encode_dispatch(level, s.data() + 4096, src_size, block_size, slots, stride, sizes, nb, with_checksum ? 1u : 0u);
+            zxc_encode_dispatch(level, in, src_size, block_size, slots, stride, sizes, nb, with_checksum ? 1u : 0u, dict_size);
         }, b, nb, 64);
     }
     return 0;

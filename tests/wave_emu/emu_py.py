@@ -43,19 +43,19 @@ class Emu:
         jobs["out_len"] = np.minimum(bs, total - np.arange(n, dtype=np.int64) * bs).astype(np.uint32)
         return jobs, *self.decode_jobs(comp, jobs, total, bs, verify_trailer=bool(table["has_checksum"]) and kw.pop("verify", False), **kw)
 
-    def encode(self, data: bytes, level=3, block_size=65536, checksum=False, seekable=True) -> bytes:
+    def encode(self, data: bytes, level=3, block_size=65536, checksum=False, seekable=True, dict_=None, dict_id=0) -> bytes:
         """The encode kernels on the emulator, one wavefront per block, assembled into a v8 archive the way
         zxc_compress (zxc_host.c) does: file header, blocks, EOF block, optional seek table, footer."""
         import oracle_py
         L = self.lib
         L.emu_encode_slot_stride.restype = C.c_uint32
-        L.emu_encode_blocks.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.emu_encode_blocks.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint32]
         nb = (len(data) + block_size - 1) // block_size
         stride = L.emu_encode_slot_stride(block_size)
         slots = C.create_string_buffer(max(nb * stride, 1))
         sizes = np.zeros(max(nb, 1), dtype=np.uint32)
         if nb:
-            L.emu_encode_blocks(data, len(data), block_size, level, int(checksum), slots, sizes.ctypes.data)
+            L.emu_encode_blocks(data, len(data), block_size, level, int(checksum), slots, sizes.ctypes.data, dict_, len(dict_) if dict_ else 0)
         O = oracle_py.Oracle().lib
         O.zxo_hash16.argtypes = [C.c_char_p]
         O.zxo_hash8.argtypes = [C.c_char_p]
@@ -63,7 +63,9 @@ class Emu:
         hdr[0:4] = (0x9CB02EF5).to_bytes(4, "little")
         hdr[4] = 8
         hdr[5] = block_size.bit_length() - 1
-        hdr[6] = 0x80 if checksum else 0
+        hdr[6] = (0x80 if checksum else 0) | (0x40 if dict_ else 0)
+        if dict_:
+            hdr[7:11] = int(dict_id).to_bytes(4, "little")  # (docs/FORMAT.md §3: dict_id at byte 7 when HAS_DICTIONARY)
         hdr[14:16] = int(O.zxo_hash16(bytes(hdr))).to_bytes(2, "little")
         out = bytearray(hdr)
         gh = 0

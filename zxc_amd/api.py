@@ -108,9 +108,15 @@ def get_decompressed_size(comp: bytes) -> int:
     return int(lib().zxc_get_decompressed_size(comp, len(comp)))
 
 
-def compress(data: bytes, level=3, block_size=65536, seekable=True, checksum=False, raise_on_error=True):
+def compress(data: bytes, level=3, block_size=65536, seekable=True, checksum=False, raise_on_error=True, dict_=None,
+             dict_huf=None):
     """zxc_compress(): host buffer in, v8 archive out (blocks encoded on the GPU)."""
     o = _CompressOpts(level=level, block_size=block_size, seekable=int(seekable), checksum_enabled=int(checksum))
+    if dict_:
+        _keep = (C.create_string_buffer(dict_, len(dict_)), C.create_string_buffer(dict_huf, 128) if dict_huf else None)
+        o.dict = C.cast(_keep[0], C.c_void_p)
+        o.dict_size = len(dict_)
+        o.dict_huf = C.cast(_keep[1], C.c_void_p) if dict_huf else None
     cap = int(lib().zxc_compress_bound(len(data)))
     out = C.create_string_buffer(max(cap, 64))
     rc = lib().zxc_compress(data, len(data), out, cap, C.byref(o))

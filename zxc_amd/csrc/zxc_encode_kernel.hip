@@ -136,7 +136,7 @@ template <uint32_t HB, uint32_t CWB, bool GHI>
 __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src, uint64_t src_size, uint32_t block_size,
                                                  uint8_t* __restrict__ slots, uint32_t slot_stride,
                                                  uint32_t* __restrict__ sizes, uint32_t n_blocks, uint32_t with_checksum,
-                                                 uint32_t depth, uint32_t sufficient, uint32_t lazy) {
+                                                 uint32_t depth, uint32_t sufficient, uint32_t lazy, uint32_t dict_size) {
     constexpr uint32_t HSIZE = 1u << HB;
     constexpr uint32_t CW = CWB ? (1u << CWB) : 1u;
     constexpr uint32_t CWM = CW - 1u;
@@ -146,9 +146,14 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) return;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    const uint8_t* in = src + (uint64_t)b * block_size;
+    // With a dictionary (reference: zxc_lz_seed_dict + the [dict | block] buffer of zxc_compress_block,
+    // src/lib/zxc_dispatch.c:1688-1697) `src` holds one [dict | block] image per block (zxc_prepend_dict_kernel):
+    // positions [0, D) are the dictionary — inserted into the tables, never parsed — and the block starts at D.
+    const uint32_t D = dict_size;
+    const uint8_t* in = src + (uint64_t)b * ((uint64_t)block_size + D);
     const uint64_t remain = src_size - (uint64_t)b * block_size;
-    const uint32_t n = remain < block_size ? (uint32_t)remain : block_size;
+    const uint32_t nblk = remain < block_size ? (uint32_t)remain : block_size;  // bytes of the block itself
+    const uint32_t n = D + nblk;
     uint8_t* slot = slots + (uint64_t)b * slot_stride;
     uint8_t* lit_out = slot + 20;
     const uint32_t max_seq = block_size / 5u + 16u;
@@ -163,18 +168,50 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     enc_lds_fence();
 
     uint32_t seq_count = 0, lit_count = 0, ext_count = 0, max_off = 0;
-    uint32_t pos = 0;     // next position the parse will look at
-    uint32_t anchor = 0;  // end of the last emitted match
+    uint32_t pos = D;     // next position the parse will look at
+    uint32_t anchor = D;  // end of the last emitted match
     const uint32_t limit = n > ENC_MARGIN + 8u ? n - ENC_MARGIN - 8u : 0u;  // last position that may start a match (exclusive)
     bool overflow = false;
 
-    uint32_t c0 = 0;
+    // publish positions of a chunk: chain link = distance to the old head, head = own position
+    auto publish = [&](uint32_t i, bool ins, uint32_t h, uint32_t d0) {
+        if (ins && CWB) chain[i & CWM] = (uint16_t)d0;
+        // head: the highest position of a bucket must win whatever order the hardware applies colliding stores in
+        bool want = ins;
+        for (;;) {
+            if (want) ht[h] = (uint16_t)i;
+            enc_lds_fence();
+            const uint32_t behind = ins ? ((i - (uint32_t)ht[h]) & 0xFFFFu) : 0u;  // 0: mine is in; 1..63: an earlier lane's
+            want = behind != 0u && behind < 64u;
+            if (__ballot(want) == 0ull) break;
+            enc_lds_fence();
+        }
+        enc_lds_fence();
+    };
+    auto hash_of = [&](uint64_t v) -> uint32_t {  // zxc_hash_func, src/lib/zxc_compress.c:45-53: 5-byte / 4-byte variants
+        if (GHI) return (((uint32_t)v ^ ((uint32_t)v >> 15)) * 0x2D35182Du) >> (32u - HB);
+        return (uint32_t)(((v & 0xFFFFFFFFFFull) * 0x2545F4914F6CDD1Dull) >> (64u - HB));
+    };
+    // dictionary positions seed the tables (no search, no parse)
+    for (uint32_t c0s = 0; c0s < D; c0s += 64u) {
+        const uint32_t i = c0s + (uint32_t)lane;
+        const bool ins = i < D && i < limit;
+        uint32_t h = 0, d0 = 0;
+        if (ins) {
+            h = hash_of(e_ld64(in + i));
+            d0 = (i - (uint32_t)ht[h]) & 0xFFFFu;
+            if (d0 > i) d0 = 0;
+        }
+        enc_lds_fence();
+        publish(i, ins, h, d0);
+    }
+
+    uint32_t c0 = D & ~63u;
     v4u v_next = {0, 0, 0, 0};  // 16 bytes at every position of the next chunk
-    if ((uint32_t)lane < limit) v_next = e_ld128(in + lane);
-    uint32_t c_next = 0;
+    uint32_t c_next = 0xFFFFFFFFu;
     while (c0 < n) {
         const uint32_t i = c0 + (uint32_t)lane;
-        const bool can = i < limit;
+        const bool can = i < limit && i >= D;
         uint64_t v = 0, vh = 0;
         if (c_next != c0 && can) v_next = e_ld128(in + i);  // (a long match skipped ahead: the prefetch was for another chunk)
         {   // request the following chunk's bytes now; they arrive while this chunk is matched, parsed and emitted
@@ -184,11 +221,10 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             const uint32_t i2 = c_next + (uint32_t)lane;
             if (i2 < limit) v_next = e_ld128(in + i2);
         }
-        // ---- 1. hash -> head candidate (zxc_hash_func, src/lib/zxc_compress.c:45-53: 5-byte / 4-byte variants)
+        // ---- 1. hash -> head candidate
         uint32_t h = 0, d0 = 0;
         if (can) {
-            if (GHI) h = (((uint32_t)v ^ ((uint32_t)v >> 15)) * 0x2D35182Du) >> (32u - HB);
-            else h = (uint32_t)(((v & 0xFFFFFFFFFFull) * 0x2545F4914F6CDD1Dull) >> (64u - HB));
+            h = hash_of(v);
             d0 = (i - (uint32_t)ht[h]) & 0xFFFFu;  // entries hold 16 bits of a position; every candidate is verified
             if (d0 > i) d0 = 0;                    // (0: none)
         }
@@ -270,20 +306,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         // ---- 3. publish this chunk's positions: lookups above saw only earlier chunks
         __builtin_amdgcn_wave_barrier();
         enc_lds_fence();
-        if (can && CWB) chain[i & CWM] = (uint16_t)d0;
-        // head: the highest position of a bucket must win whatever order the hardware applies colliding stores in
-        {
-            bool want = can;
-            for (;;) {
-                if (want) ht[h] = (uint16_t)i;
-                enc_lds_fence();
-                const uint32_t behind = can ? ((i - (uint32_t)ht[h]) & 0xFFFFu) : 0u;  // 0: mine is in; 1..63: an earlier lane's
-                want = behind != 0u && behind < 64u;
-                if (__ballot(want) == 0ull) break;
-                enc_lds_fence();
-            }
-        }
-        enc_lds_fence();
+        publish(i, can, h, d0);
 
         // ---- 4. scalar parse of the chunk: greedy + the level's lazy probes + backward extension
         uint64_t sel = 0;
@@ -482,24 +505,24 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     uint32_t behind = sz_tok + sz_off + ext_count;
     const uint32_t pad = behind < 32u ? 32u - behind : 0u;
     const uint32_t payload = 12u + desc + lit_sec + behind + pad;
-    if (overflow || 8u + payload >= n || n < 64u) {
+    if (overflow || 8u + payload >= nblk || nblk < 64u) {
         // RAW block (reference: zxc_encode_block_raw, src/lib/zxc_compress.c:2004-2023)
-        for (uint32_t o = 16u * lane; o < n; o += 1024u) {
-            if (o + 16u <= n) { const v4u t = e_ld128(in + o); __builtin_memcpy(slot + 8 + o, &t, 16); }
-            else for (uint32_t k = o; k < n; k++) slot[8 + k] = in[k];
+        for (uint32_t o = 16u * lane; o < nblk; o += 1024u) {
+            if (o + 16u <= nblk) { const v4u t = e_ld128(in + D + o); __builtin_memcpy(slot + 8 + o, &t, 16); }
+            else for (uint32_t k = o; k < nblk; k++) slot[8 + k] = in[D + k];
         }
         if (lane == 0) {
-            uint64_t hv = (uint64_t)0 | ((uint64_t)n << 24);  // type 0, flags 0, reserved 0, comp_size le32 @3
+            uint64_t hv = (uint64_t)0 | ((uint64_t)nblk << 24);  // type 0, flags 0, reserved 0, comp_size le32 @3
             const uint8_t crc = hdr_hash8(hv);
             hv |= (uint64_t)crc << 56;
             __builtin_memcpy(slot, &hv, 8);
         }
-        uint32_t total = 8u + n;
+        uint32_t total = 8u + nblk;
         if (with_checksum) {  // trailer = checksum of the payload (zxc_compress.c:2060-2071); read back through L2
             __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const uint32_t ck = wave_checksum32(slot + 8, n, lane);
+            const uint32_t ck = wave_checksum32(slot + 8, nblk, lane);
             if (lane == 0) __builtin_memcpy(slot + total, &ck, 4);
             total += 4u;
         }
@@ -559,14 +582,29 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     extern "C" __global__ void __launch_bounds__(64, waves) name(                                                      \
         const uint8_t* __restrict__ src, uint64_t src_size, uint32_t block_size, uint8_t* __restrict__ slots,          \
         uint32_t slot_stride, uint32_t* __restrict__ sizes, uint32_t n_blocks, uint32_t with_checksum, uint32_t depth, \
-        uint32_t sufficient, uint32_t lazy) {                                                                          \
+        uint32_t sufficient, uint32_t lazy, uint32_t dict_size) {                                                      \
         encode_one_block<hb, cwb, ghi>(src, src_size, block_size, slots, slot_stride, sizes, n_blocks, with_checksum,  \
-                                       depth, sufficient, lazy);                                                       \
+                                       depth, sufficient, lazy, dict_size);                                            \
     }
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l1, 12u, 0u, true, 5)    // level 1
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l2, 12u, 11u, true, 3)   // level 2
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l34, 13u, 12u, false, 2) // levels 3-4
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l57, 14u, 14u, false, 1) // levels 5-7
+
+// [dict | block b] images for the dictionary path: work + b * (block_size + dict_size)
+extern "C" __global__ void __launch_bounds__(64)
+zxc_prepend_dict_kernel(const uint8_t* __restrict__ src, uint64_t src_size, uint32_t block_size, const uint8_t* __restrict__ dict,
+                        uint32_t dict_size, uint8_t* __restrict__ work, uint32_t n_blocks) {
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const int lane = threadIdx.x;
+    uint8_t* w = work + (uint64_t)b * ((uint64_t)block_size + dict_size);
+    for (uint32_t o = lane; o < dict_size; o += 64u) w[o] = dict[o];
+    const uint64_t remain = src_size - (uint64_t)b * block_size;
+    const uint32_t n = remain < block_size ? (uint32_t)remain : block_size;
+    const uint8_t* s = src + (uint64_t)b * block_size;
+    for (uint32_t o = lane; o < n; o += 64u) w[dict_size + o] = s[o];
+}
 
 // Compaction: block b's bytes [slot, slot+sizes[b]) -> out + offsets[b] (+ optional 4-byte trailer gap).
 extern "C" __global__ void __launch_bounds__(64)

@@ -29,11 +29,13 @@ extern "C" __global__ void zxc_decode_blocks_dict_kernel(const uint8_t* comp, co
 #define ZXC_ENCODE_DECL(name)                                                                                          \
     extern "C" __global__ void name(const uint8_t* src, uint64_t src_size, uint32_t block_size, uint8_t* slots,        \
                                     uint32_t slot_stride, uint32_t* sizes, uint32_t n_blocks, uint32_t with_checksum,  \
-                                    uint32_t depth, uint32_t sufficient, uint32_t lazy);
+                                    uint32_t depth, uint32_t sufficient, uint32_t lazy, uint32_t dict_size);
 ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l1)
 ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l2)
 ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l34)
 ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l57)
+extern "C" __global__ void zxc_prepend_dict_kernel(const uint8_t* src, uint64_t src_size, uint32_t block_size, const uint8_t* dict,
+                                                   uint32_t dict_size, uint8_t* work, uint32_t n_blocks);
 extern "C" __global__ void zxc_gather_blocks_kernel(const uint8_t* slots, uint32_t slot_stride, const uint32_t* sizes,
                                                     const uint64_t* offsets, uint8_t* out, uint32_t n_blocks);
 
@@ -224,23 +226,46 @@ int zxc_hip_current_device(void) { return current_device(); }
 
 uint32_t zxc_mi355x_encode_slot_stride(uint32_t block_size) { return 2u * block_size + 512u; }
 
-int zxc_mi355x_encode_blocks_device(const void* d_src, uint64_t src_size, uint32_t block_size, int level,
-                                    int with_checksum, void* d_slots, uint32_t* d_sizes, void* stream) {
+static int encode_launch(const void* d_src, uint64_t src_size, uint32_t block_size, int level, int with_checksum,
+                         const void* d_dict, uint32_t dict_size, void* d_work, void* d_slots, uint32_t* d_sizes, void* stream) {
     // the level picks the kernel entry (table geometry = occupancy, GHI / GLO) and the search effort (zxc_encode_levels.h)
     if (src_size == 0) return ZXC_OK;
-    if (!d_src || !d_slots || !d_sizes) return ZXC_ERROR_NULL_INPUT;
+    if (!d_src || !d_slots || !d_sizes || (dict_size && (!d_dict || !d_work))) return ZXC_ERROR_NULL_INPUT;
     if (block_size < (1u << 12) || block_size > (1u << 21) || (block_size & (block_size - 1u))) return ZXC_ERROR_BAD_BLOCK_SIZE;
+    if (dict_size > 65535u) return ZXC_ERROR_DICT_TOO_LARGE;
     if (current_device() < 0) return ZXC_ERROR_GPU_UNAVAILABLE;
     const uint64_t nb64 = (src_size + block_size - 1u) / block_size;
     if (nb64 > 0x7FFFFFFFull) return ZXC_ERROR_BAD_BLOCK_SIZE;
     const uint32_t nb = (uint32_t)nb64;
+    const uint8_t* in = (const uint8_t*)d_src;
+    if (dict_size) {  // [dict | block] image per block: the dictionary seeds every block's tables
+        hipLaunchKernelGGL(zxc_prepend_dict_kernel, dim3(nb), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_src, src_size,
+                           block_size, (const uint8_t*)d_dict, dict_size, (uint8_t*)d_work, nb);
+        in = (const uint8_t*)d_work;
+    }
     const zxc_enc_level_t lp = zxc_enc_level(level);
     auto kern = lp.entry == 0 ? zxc_encode_blocks_kernel_l1 : lp.entry == 1 ? zxc_encode_blocks_kernel_l2
               : lp.entry == 2 ? zxc_encode_blocks_kernel_l34 : zxc_encode_blocks_kernel_l57;
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_src, src_size, block_size,
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(64), 0, (hipStream_t)stream, in, src_size, block_size,
                        (uint8_t*)d_slots, zxc_mi355x_encode_slot_stride(block_size), d_sizes, nb, with_checksum ? 1u : 0u,
-                       lp.depth, lp.sufficient, lp.lazy);
+                       lp.depth, lp.sufficient, lp.lazy, dict_size);
     return hipGetLastError() == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
+}
+
+int zxc_mi355x_encode_blocks_device(const void* d_src, uint64_t src_size, uint32_t block_size, int level,
+                                    int with_checksum, void* d_slots, uint32_t* d_sizes, void* stream) {
+    return encode_launch(d_src, src_size, block_size, level, with_checksum, NULL, 0, NULL, d_slots, d_sizes, stream);
+}
+
+uint64_t zxc_mi355x_encode_dict_work_size(uint64_t src_size, uint32_t block_size, uint32_t dict_size) {
+    const uint64_t nb = block_size ? (src_size + block_size - 1u) / block_size : 0;
+    return nb * ((uint64_t)block_size + dict_size) + 64u;
+}
+
+int zxc_mi355x_encode_blocks_dict_device(const void* d_src, uint64_t src_size, uint32_t block_size, int level,
+                                         int with_checksum, const void* d_dict, uint32_t dict_size, void* d_work,
+                                         void* d_slots, uint32_t* d_sizes, void* stream) {
+    return encode_launch(d_src, src_size, block_size, level, with_checksum, d_dict, dict_size, d_work, d_slots, d_sizes, stream);
 }
 
 int zxc_mi355x_gather_blocks_device(const void* d_slots, uint32_t block_size, const uint32_t* d_sizes,

@@ -437,7 +437,8 @@ int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const 
     if (dict_size > ZXC_DICT_SIZE_MAX) return ZXC_ERROR_DICT_TOO_LARGE;
     if (block_size < ZXC_BLOCK_SIZE_MIN || block_size > ZXC_BLOCK_SIZE_MAX || (block_size & (block_size - 1)))
         return ZXC_ERROR_BAD_BLOCK_SIZE;
-    if (dict_size != 0) return ZXC_ERROR_GPU_UNSUPPORTED; /* dictionary: next scope row */
+    const uint8_t* dict = dict_size ? (const uint8_t*)opts->dict : NULL;
+    const uint8_t* dict_huf = dict_size ? (const uint8_t*)opts->dict_huf : NULL;
     if (dst_capacity < ZXC_FILE_HEADER_SIZE) return ZXC_ERROR_DST_TOO_SMALL;
 
     /* file header (src/lib/zxc_common.c:534-558) */
@@ -448,6 +449,10 @@ int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const 
     while (((size_t)1 << lg) < block_size) lg++;
     dst[5] = lg;
     dst[6] = checksum_enabled ? 0x80 : 0; /* HAS_CHECKSUM | algo 0 (rapidhash) */
+    if (dict_size) { /* HAS_DICTIONARY + dict_id binding content (and shared table), src/lib/zxc_common.c:546-553 */
+        dst[6] |= 0x40;
+        wr32(dst + 7, dict_id_of(dict, dict_size, dict_huf));
+    }
     const uint16_t crc = hdr_hash16(dst);
     dst[14] = (uint8_t)crc;
     dst[15] = (uint8_t)(crc >> 8);
@@ -468,12 +473,17 @@ int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const 
         void* d_sizes = zxc_mi355x_malloc((size_t)nb * 4);
         void* d_offs = zxc_mi355x_malloc((size_t)nb * 8);
         void* d_out = NULL;
+        void* d_dict = dict_size ? zxc_mi355x_malloc(dict_size + 64) : NULL;
+        void* d_work = dict_size ? zxc_mi355x_malloc((size_t)zxc_mi355x_encode_dict_work_size(src_size, (uint32_t)block_size, (uint32_t)dict_size)) : NULL;
         int64_t rc = ZXC_ERROR_MEMORY;
-        if (sizes && offs && d_src && d_slots && d_sizes && d_offs) {
+        if (sizes && offs && d_src && d_slots && d_sizes && d_offs && (!dict_size || (d_dict && d_work))) {
             rc = zxc_mi355x_memcpy_h2d(d_src, src, src_size);
+            if (rc == ZXC_OK && dict_size) rc = zxc_mi355x_memcpy_h2d(d_dict, dict, dict_size);
             if (rc == ZXC_OK)
-                rc = zxc_mi355x_encode_blocks_device(d_src, src_size, (uint32_t)block_size, level, checksum_enabled,
-                                                     d_slots, (uint32_t*)d_sizes, NULL);
+                rc = dict_size ? zxc_mi355x_encode_blocks_dict_device(d_src, src_size, (uint32_t)block_size, level, checksum_enabled,
+                                                                      d_dict, (uint32_t)dict_size, d_work, d_slots, (uint32_t*)d_sizes, NULL)
+                               : zxc_mi355x_encode_blocks_device(d_src, src_size, (uint32_t)block_size, level, checksum_enabled,
+                                                                 d_slots, (uint32_t*)d_sizes, NULL);
             if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(NULL);
             if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(sizes, d_sizes, (size_t)nb * 4);
             uint64_t total = 0;
@@ -502,6 +512,8 @@ int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const 
         zxc_mi355x_free(d_sizes);
         zxc_mi355x_free(d_offs);
         zxc_mi355x_free(d_out);
+        zxc_mi355x_free(d_dict);
+        zxc_mi355x_free(d_work);
         free(offs);
         if (rc != ZXC_OK) { free(sizes); return rc; }
     }
@@ -857,7 +869,9 @@ int64_t zxc_compress_block(zxc_cctx* cctx, const void* src, const size_t src_siz
     const int checksum_enabled = opts ? opts->checksum_enabled : cctx->checksum;
     int level = (opts && opts->level > 0) ? opts->level : cctx->level;
     if (level > ZXC_LEVEL_ULTRA) level = ZXC_LEVEL_ULTRA;
-    if (opts && opts->dict && opts->dict_size > 0) return ZXC_ERROR_GPU_UNSUPPORTED; /* dictionary encode: not on the device yet */
+    const uint8_t* b_dict = (opts && opts->dict && opts->dict_size > 0) ? (const uint8_t*)opts->dict : NULL;
+    const size_t b_dict_size = b_dict ? opts->dict_size : 0;
+    if (b_dict_size > ZXC_DICT_SIZE_MAX) return ZXC_ERROR_DICT_TOO_LARGE;
     const size_t want_bs = (opts && opts->block_size > 0) ? opts->block_size : cctx->block_size;
     const size_t min_bs = block_size_ceil(src_size);
     const size_t bs = want_bs > min_bs ? want_bs : min_bs; /* one block: block_size >= src_size */
@@ -870,13 +884,18 @@ int64_t zxc_compress_block(zxc_cctx* cctx, const void* src, const size_t src_siz
     void* d_src = zxc_mi355x_malloc(src_size + 64);
     void* d_slot = zxc_mi355x_malloc(stride);
     void* d_size = zxc_mi355x_malloc(4);
+    void* d_dict = b_dict_size ? zxc_mi355x_malloc(b_dict_size + 64) : NULL;
+    void* d_work = b_dict_size ? zxc_mi355x_malloc((size_t)zxc_mi355x_encode_dict_work_size(src_size, (uint32_t)bs, (uint32_t)b_dict_size)) : NULL;
     int64_t rc = ZXC_ERROR_MEMORY;
     uint32_t csize = 0;
-    if (d_src && d_slot && d_size) {
+    if (d_src && d_slot && d_size && (!b_dict_size || (d_dict && d_work))) {
         rc = zxc_mi355x_memcpy_h2d(d_src, src, src_size);
+        if (rc == ZXC_OK && b_dict_size) rc = zxc_mi355x_memcpy_h2d(d_dict, b_dict, b_dict_size);
         if (rc == ZXC_OK)
-            rc = zxc_mi355x_encode_blocks_device(d_src, src_size, (uint32_t)bs, level, checksum_enabled, d_slot,
-                                                 (uint32_t*)d_size, NULL);
+            rc = b_dict_size ? zxc_mi355x_encode_blocks_dict_device(d_src, src_size, (uint32_t)bs, level, checksum_enabled, d_dict,
+                                                                    (uint32_t)b_dict_size, d_work, d_slot, (uint32_t*)d_size, NULL)
+                             : zxc_mi355x_encode_blocks_device(d_src, src_size, (uint32_t)bs, level, checksum_enabled, d_slot,
+                                                               (uint32_t*)d_size, NULL);
         if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(NULL);
         if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(&csize, d_size, 4);
         if (rc == ZXC_OK && csize > dst_capacity) rc = ZXC_ERROR_DST_TOO_SMALL;
@@ -885,6 +904,8 @@ int64_t zxc_compress_block(zxc_cctx* cctx, const void* src, const size_t src_siz
     zxc_mi355x_free(d_src);
     zxc_mi355x_free(d_slot);
     zxc_mi355x_free(d_size);
+    zxc_mi355x_free(d_dict);
+    zxc_mi355x_free(d_work);
     return rc == ZXC_OK ? (int64_t)csize : rc;
 }
 
