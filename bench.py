@@ -70,7 +70,8 @@ def build_rank_corpus(first, last, level, block_size, pool, dev, checksum=False)
     hdr = eof = None
     first_tile_comp = None
     src = ""
-    with ThreadPoolExecutor(max_workers=max(1, min(8, len(tiles)))) as tp:
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    with ThreadPoolExecutor(max_workers=max(1, min(16, len(tiles), (os.cpu_count() or 1) // world // 2))) as tp:
         futs = []
         for t in tiles:
             data, src = tile_bytes(t, block_size, pool)
@@ -358,9 +359,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--tiles", type=int, default=int(os.environ.get("ZXC_BENCH_TILES", "10")),
-                    help="corpus tiles per GPU, 211 943 424 B of unique silesia-mix plaintext each (10 = 2.1 GB decoded "
-                         "per GPU; 41 = configs[3]'s 64 GiB over 8 GPUs)")
+    ap.add_argument("--tiles", type=int, default=int(os.environ.get("ZXC_BENCH_TILES", "41")),
+                    help="corpus tiles per GPU, 211 943 424 B of unique silesia-mix plaintext each (41 = 8.7 GB decoded / "
+                         "4.4 GB compressed per GPU = configs[3]'s 64 GiB over 8 GPUs; levels 6-7: pass --tiles 4, the "
+                         "reference encoder prepares them at ~8 MB/s per thread)")
     ap.add_argument("--enc-mib", type=int, default=1024, help="(encode mode) MiB of unique enwik-like text per GPU (configs[2]: 1 GiB)")
     ap.add_argument("--level", type=int, default=3)
     ap.add_argument("--block-size", type=int, default=65536)
@@ -465,7 +467,7 @@ def main():
         achieved = algo_bytes / avg_kernel_s / 1e9
         cfg = "configs[4]" if args.level == 7 else "configs[1]" if args.level == 3 else f"configs[1] at level {args.level}"
         if world > 1:
-            cfg = "configs[3] (scaled: --tiles 41 is the full 64 GiB at 8 GPUs)"
+            cfg = f"configs[3] ({world * args.tiles * 211943424 / 2**30:.1f} GiB corpus over {world} GPUs)"
         traffic = pmc_traffic(args, args.tiles)
         line = {
             "metric": f"seekable decode GB/s (level {args.level}, {bs >> 10} KiB independent blocks, HBM-resident in/out"

@@ -82,9 +82,6 @@ def test_range_helpers():
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
-    costs = [1, 100, 1, 1, 100, 1, 1, 1]
-    rr = shard.byte_balanced_ranges(2, costs)
-    assert rr[0][0] == 0 and rr[-1][1] == len(costs) and rr[0][1] == rr[1][0]
 
 
 def _bench_worker(rank, world, port, q, tiles_per_gpu):

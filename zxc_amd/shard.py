@@ -8,19 +8,3 @@ def block_range(rank: int, world: int, n_blocks: int):
         raise ValueError("rank out of range")
     return (rank * n_blocks) // world, ((rank + 1) * n_blocks) // world
 
-
-def byte_balanced_ranges(world: int, costs):
-    """Contiguous split by cumulative cost (comp_size + decomp_size per block) instead of count."""
-    total = float(sum(costs))
-    bounds = [0]
-    acc = 0.0
-    g = 1
-    for i, c in enumerate(costs):
-        acc += c
-        while g < world and acc >= total * g / world:
-            bounds.append(i + 1)
-            g += 1
-    while len(bounds) < world:
-        bounds.append(len(costs))
-    bounds.append(len(costs))
-    return [(bounds[g], bounds[g + 1]) for g in range(world)]
