@@ -6,5 +6,6 @@
 #include "zxc_opts.h"
 #include "zxc_buffer.h"
 #include "zxc_seekable.h"
+#include "zxc_dict.h"
 #include "zxc_mi355x.h"
 #endif

@@ -65,6 +65,49 @@ def test_block_bounds_and_dict_id_match_reference(product, ref):
     assert P.zxc_get_dict_id(b"\0" * 16, 16) == 0 and P.zxc_get_dict_id(b"", 0) == 0
 
 
+def test_zxd_container_helpers_match_reference(product, ref):
+    """zxc_dict_id / zxc_dict_load / zxc_dict_save / zxc_dict_get_id / zxc_dict_huf (reference src/lib/zxc_dict.c:35-205):
+    same ids, same bytes, same error codes as the unmodified reference on the conformance .zxd files and on damaged ones."""
+    def bind(L):
+        L.zxc_dict_id.restype = C.c_uint32
+        L.zxc_dict_id.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+        L.zxc_dict_get_id.restype = C.c_uint32
+        L.zxc_dict_get_id.argtypes = [C.c_char_p, C.c_size_t]
+        L.zxc_dict_save_bound.restype = C.c_size_t
+        L.zxc_dict_save_bound.argtypes = [C.c_size_t]
+        L.zxc_dict_save.restype = C.c_int64
+        L.zxc_dict_save.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_void_p, C.c_size_t]
+        L.zxc_dict_load.restype = C.c_int
+        L.zxc_dict_load.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                    C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
+        L.zxc_dict_huf.restype = C.c_void_p
+        L.zxc_dict_huf.argtypes = [C.c_char_p, C.c_size_t]
+        return L
+    P, R = bind(C.CDLL(product.lib_path())), bind(ref.lib)
+    for name in ("dict_http.zxd", "dict_text.zxd"):
+        zxd = read(f"conformance/valid/{name}")
+        n = zxd[6] | (zxd[7] << 8)
+        content, huf = zxd[16:16 + n], zxd[16 + n:16 + n + 128]
+        assert P.zxc_dict_id(content, n, huf) == R.zxc_dict_id(content, n, huf) == P.zxc_dict_get_id(zxd, len(zxd))
+        assert P.zxc_dict_id(content, n, None) == R.zxc_dict_id(content, n, None)
+        assert P.zxc_dict_save_bound(n) == R.zxc_dict_save_bound(n) == len(zxd)
+        out = C.create_string_buffer(len(zxd))
+        assert P.zxc_dict_save(content, n, huf, out, len(zxd)) == len(zxd) and out.raw == zxd
+        assert P.zxc_dict_save(content, n, huf, out, len(zxd) - 1) == R.zxc_dict_save(content, n, huf, out, len(zxd) - 1) == -2
+        for mutate in (None, 0, 4, 6, 9, 14, 20, len(zxd) - 1):
+            m = bytearray(zxd)
+            if mutate is not None:
+                m[mutate] ^= 0x10
+            res = []
+            for L in (P, R):
+                cp, cs, hp, did = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_uint32()
+                rc = L.zxc_dict_load(bytes(m), len(m), C.byref(cp), C.byref(cs), C.byref(hp), C.byref(did))
+                res.append((rc, cs.value if rc == 0 else 0, did.value if rc == 0 else 0))
+            assert res[0] == res[1], (name, mutate, res)
+        assert P.zxc_dict_load(zxd[:10], 10, C.byref(C.c_void_p()), C.byref(C.c_size_t()), None, None) == -3
+        assert bool(P.zxc_dict_huf(zxd, len(zxd))) and not P.zxc_dict_huf(b"\0" * 200, 200)
+
+
 def test_container_errors_need_no_gpu(product, manifest):
     """Header-level rejections happen on the host before any device work, with the
     reference's pinned codes (conformance/test_conformance.c:228-249)."""

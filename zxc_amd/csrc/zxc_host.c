@@ -152,6 +152,76 @@ static uint32_t dict_id_of(const uint8_t* dict, size_t n, const uint8_t* huf) {
     return (uint32_t)(h ^ (h >> 32));
 }
 
+/* .zxd container (reference src/lib/zxc_dict.c:35-205): 16-byte header {magic, version, flags, content size u16,
+ * dict_id u32, reserved u16, CRC16 over the header with bytes 12-15 zeroed} + content + 128-byte table */
+#define DICT_MAGIC 0x9CB0D1C7u
+#define DICT_VERSION 1
+#define DICT_HDR 16
+static uint16_t hdr_hash16(const uint8_t* p);
+
+uint32_t zxc_dict_id(const void* dict, size_t dict_size, const void* huf_lengths) {
+    return dict_id_of((const uint8_t*)dict, dict_size, (const uint8_t*)huf_lengths);
+}
+uint32_t zxc_dict_get_id(const void* buf, const size_t buf_size) {
+    if (!buf || buf_size < DICT_HDR) return 0;
+    const uint8_t* p = (const uint8_t*)buf;
+    return rd32(p) == DICT_MAGIC ? rd32(p + 8) : 0;
+}
+size_t zxc_dict_save_bound(const size_t content_size) { return DICT_HDR + content_size + ZXC_HUF_TABLE_SIZE; }
+int64_t zxc_dict_save(const void* content, const size_t content_size, const void* huf_lengths, void* buf,
+                      const size_t buf_capacity) {
+    if (!content || content_size == 0 || !huf_lengths) return ZXC_ERROR_NULL_INPUT;
+    if (content_size > ZXC_DICT_SIZE_MAX) return ZXC_ERROR_DICT_TOO_LARGE;
+    const size_t total = zxc_dict_save_bound(content_size);
+    if (buf_capacity < total) return ZXC_ERROR_DST_TOO_SMALL;
+    uint8_t* d = (uint8_t*)buf;
+    wr32(d, DICT_MAGIC);
+    d[4] = DICT_VERSION;
+    d[5] = 0;
+    d[6] = (uint8_t)content_size;
+    d[7] = (uint8_t)(content_size >> 8);
+    wr32(d + 8, dict_id_of((const uint8_t*)content, content_size, (const uint8_t*)huf_lengths));
+    wr32(d + 12, 0);
+    const uint16_t crc = hdr_hash16(d);
+    d[14] = (uint8_t)crc;
+    d[15] = (uint8_t)(crc >> 8);
+    memcpy(d + DICT_HDR, content, content_size);
+    memcpy(d + DICT_HDR + content_size, huf_lengths, ZXC_HUF_TABLE_SIZE);
+    return (int64_t)total;
+}
+int zxc_dict_load(const void* buf, const size_t buf_size, const void** content_out, size_t* content_size_out,
+                  const void** huf_out, uint32_t* dict_id_out) {
+    if (!buf || !content_out || !content_size_out) return ZXC_ERROR_NULL_INPUT;
+    if (buf_size < DICT_HDR) return ZXC_ERROR_SRC_TOO_SMALL;
+    const uint8_t* src = (const uint8_t*)buf;
+    if (rd32(src) != DICT_MAGIC) return ZXC_ERROR_BAD_MAGIC;
+    if (src[4] != DICT_VERSION) return ZXC_ERROR_BAD_VERSION;
+    const size_t n = rd16(src + 6);
+    if (n == 0) return ZXC_ERROR_CORRUPT_DATA;
+    if (buf_size < DICT_HDR + n + ZXC_HUF_TABLE_SIZE) return ZXC_ERROR_SRC_TOO_SMALL;
+    uint8_t t[DICT_HDR];
+    memcpy(t, src, DICT_HDR);
+    t[12] = t[13] = t[14] = t[15] = 0;
+    if (rd16(src + 14) != hdr_hash16(t)) return ZXC_ERROR_BAD_HEADER;
+    const uint8_t* content = src + DICT_HDR;
+    const uint8_t* huf = content + n;
+    const uint32_t id = dict_id_of(content, n, huf);
+    if (rd32(src + 8) != id) return ZXC_ERROR_BAD_CHECKSUM;
+    *content_out = content;
+    *content_size_out = n;
+    if (huf_out) *huf_out = huf;
+    if (dict_id_out) *dict_id_out = id;
+    return ZXC_OK;
+}
+const void* zxc_dict_huf(const void* buf, const size_t buf_size) {
+    if (!buf || buf_size < DICT_HDR) return NULL;
+    const uint8_t* src = (const uint8_t*)buf;
+    if (rd32(src) != DICT_MAGIC || src[4] != DICT_VERSION) return NULL;
+    const size_t n = rd16(src + 6);
+    if (n == 0 || buf_size < DICT_HDR + n + ZXC_HUF_TABLE_SIZE) return NULL;
+    return src + DICT_HDR + n;
+}
+
 /* ------------------------------------------------------------- containers */
 static int read_file_header(const uint8_t* src, size_t n, uint32_t* block_size, int* has_checksum,
                             uint32_t* dict_id) {
