@@ -62,7 +62,15 @@ def test_every_level_round_trips_and_differs_in_effort(gpu, oracle, ref, synth_i
             types.add(comp[off])
             off += s.block_comp_size(b)
         assert types <= ({0, 2} if level <= 2 else {0, 1}), (level, types)
-    assert sizes[5] < 0.93 * sizes[1] and sizes[3] < sizes[2] and sizes[7] <= sizes[5] * 1.001, sizes
+        if level >= 6:  # enc_lit = 2 (and enc_tok = 2 at level 7) somewhere in the archive
+            off2, encs = 16, set()
+            for b in range(s.num_blocks):
+                if comp[off2] == 1:
+                    encs.add((comp[off2 + 16], comp[off2 + 17]))
+                off2 += s.block_comp_size(b)
+            assert any(el == 2 for el, et in encs) and (level == 6 or any(et == 2 for el, et in encs)), (level, encs)
+    assert sizes[5] < 0.93 * sizes[1] and sizes[3] < sizes[2], sizes
+    assert sizes[6] < 0.97 * sizes[5] and sizes[7] <= sizes[6], sizes  # levels 6-7: PivCo-coded literal / token sections
     assert gpu.compress(data, 3, 65536, True) == gpu.compress(data, 3, 65536, True)  # archive bytes are deterministic
 
 

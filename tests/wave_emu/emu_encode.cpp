@@ -19,13 +19,13 @@ extern char __start_emu_lds[], __stop_emu_lds[];
 // level -> kernel entry + search effort, exactly as zxc_mi355x_encode_blocks_device (zxc_hip_shim.hip) picks them
 #include "zxc_encode_levels.h"
 static void zxc_encode_dispatch(int level, const uint8_t* src, uint64_t src_size, uint32_t block_size, uint8_t* slots,
-                                uint32_t stride, uint32_t* sizes, uint32_t nb, uint32_t ck, uint32_t dict_size) {
+                                uint32_t stride, uint32_t* sizes, uint32_t nb, uint32_t ck, uint32_t dict_size, uint8_t* hs) {
     const zxc_enc_level_t p = zxc_enc_level(level);
     switch (p.entry) {
-        case 0: zxc_encode_blocks_kernel_l1(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size); break;
-        case 1: zxc_encode_blocks_kernel_l2(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size); break;
-        case 2: zxc_encode_blocks_kernel_l34(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size); break;
-        default: zxc_encode_blocks_kernel_l57(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size); break;
+        case 0: zxc_encode_blocks_kernel_l1(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size, hs, p.huf); break;
+        case 1: zxc_encode_blocks_kernel_l2(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size, hs, p.huf); break;
+        case 2: zxc_encode_blocks_kernel_l34(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size, hs, p.huf); break;
+        default: zxc_encode_blocks_kernel_l57(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size, hs, p.huf); break;
     }
 }
 
@@ -47,10 +47,11 @@ int emu_encode_blocks(const uint8_t* src, uint64_t src_size, uint32_t block_size
             emu::run_wave([&] { zxc_prepend_dict_kernel(s.data() + 4096, src_size, block_size, dict, dict_size, work.data() + 4096, nb); }, b, nb, 64);
         in = work.data() + 4096;
     }
+    std::vector<uint8_t> hs((size_t)nb * 4u * ((size_t)block_size + 64u) + 8192, 0xEE);  // PivCo encoder scratch (levels 6-7)
     for (uint32_t b = 0; b < nb; b++) {
         memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));
         emu::run_wave([&] {
-            zxc_encode_dispatch(level, in, src_size, block_size, slots, stride, sizes, nb, with_checksum ? 1u : 0u, dict_size);
+            zxc_encode_dispatch(level, in, src_size, block_size, slots, stride, sizes, nb, with_checksum ? 1u : 0u, dict_size, hs.data() + 4096);
         }, b, nb, 64);
     }
     return 0;

@@ -127,6 +127,8 @@ __device__ __forceinline__ uint32_t prefix16(uint64_t a_lo, uint64_t a_hi, const
     return (x ? lo : 64u + hi) >> 3;
 }
 
+#include "zxc_pivco_encode.inc"
+
 // Slot layout while encoding (stride = 2*block_size + 512 bytes per block):
 //   [0,8) block header | [8,20) GLO/GHI header | literals ... | ... staging from block_size + 64: tokens (GLO: 1 B,
 //   GHI: 4-byte words), offsets (GLO), extras
@@ -136,11 +138,12 @@ template <uint32_t HB, uint32_t CWB, bool GHI>
 __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src, uint64_t src_size, uint32_t block_size,
                                                  uint8_t* __restrict__ slots, uint32_t slot_stride,
                                                  uint32_t* __restrict__ sizes, uint32_t n_blocks, uint32_t with_checksum,
-                                                 uint32_t depth, uint32_t sufficient, uint32_t lazy, uint32_t dict_size) {
+                                                 uint32_t depth, uint32_t sufficient, uint32_t lazy, uint32_t dict_size,
+                                                 uint8_t* __restrict__ huf_scratch, uint32_t huf) {
     constexpr uint32_t HSIZE = 1u << HB;
     constexpr uint32_t CW = CWB ? (1u << CWB) : 1u;
     constexpr uint32_t CWM = CW - 1u;
-    __shared__ uint16_t ht[HSIZE];     // head: low 16 bits of the most recent position with this hash
+    __shared__ __attribute__((aligned(16))) uint16_t ht[HSIZE];  // head: low 16 bits of the most recent position with this hash
     __shared__ uint16_t chain[CW];     // chain[q & CWM]: distance from q to the previous position with q's hash (0: none)
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
@@ -155,7 +158,9 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     const uint32_t nblk = remain < block_size ? (uint32_t)remain : block_size;  // bytes of the block itself
     const uint32_t n = D + nblk;
     uint8_t* slot = slots + (uint64_t)b * slot_stride;
-    uint8_t* lit_out = slot + 20;
+    // literals are gathered behind room for the widest descriptor set (levels 6-7: lit_comp + tok_comp) and slid down at the end
+    const uint32_t lit_base = (HB >= 14u && huf != 0u) ? 28u : 20u;
+    uint8_t* lit_out = slot + lit_base;
     const uint32_t max_seq = block_size / 5u + 16u;
     uint8_t* tok_st = slot + block_size + 64u;                // GLO: 1 byte per sequence; GHI: one 32-bit word
     uint8_t* off_st = tok_st + max_seq;                       // GLO: u16 per sequence
@@ -413,7 +418,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the literal section is read back with cached loads
         uint8_t* rle_out = lit_out + lit_count + 4u;         // (temp behind the literals; moved down when chosen)
-        const bool room = 24u + 2u * lit_count + 8u <= block_size + 64u;
+        const bool room = lit_base + 4u + 2u * lit_count + 8u <= block_size + 64u;
         // pass 0 sizes, pass 1 writes
         for (uint32_t pass = 0; pass < 2u && room; pass++) {
             if (pass == 1u) {
@@ -487,21 +492,48 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             }
             if (pass == 0u) rle_size = w;
         }
-        if (use_rle) {  // slide the coded section down over the raw one, behind the 4-byte descriptor
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            wave_move_down(slot + 24, rle_out, rle_size, lane);
-        }
     }
-
+    // ---- PivCo (Huffman) literal / token coding, levels 6-7 (zxc_pivco_encode.inc). Candidates are priced like the
+    // reference does (zxc_compress.c:1536-1626): size + premium * decoded bytes, premium 4/256 for Huffman and 1/256
+    // for RLE at these levels (zxc_internal.h:771-795); at least 256 symbols.
+    bool lit_huf = false, tok_huf = false;
+    uint32_t huf_lit_size = 0, huf_tok_size = 0;
+    uint8_t* hs = nullptr;
+    if (HB >= 14u && !GHI && huf != 0u && !overflow) {
+        PivEnc& PE = *reinterpret_cast<PivEnc*>(ht);  // the match finder's tables are dead now
+        static_assert(HB < 14u || sizeof(PivEnc) <= (sizeof(uint16_t) << (HB < 14u ? 14u : HB)), "PivEnc must fit the head table");
+        const uint32_t hstride = block_size + 64u;
+        hs = huf_scratch + (uint64_t)b * 4u * hstride;  // [level buffer A | level buffer B | literal section | token section]
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // literals / tokens were written with ordinary stores
+        if (lit_count >= 256u) {
+            const uint32_t tax = (lit_count * 4u) >> 8;
+            uint32_t best = lit_count;  // raw
+            if (use_rle) { const uint32_t j = rle_size + (lit_count >> 8); best = j < best ? j : best; }
+            if (best > tax + 129u) {
+                huf_lit_size = pivco_encode(lit_out, lit_count, hs + 2u * hstride, best - tax, hs, hs + hstride, PE, lane);
+                if (huf_lit_size) { lit_huf = true; use_rle = false; }
+            }
+        }
+        if (huf >= 2u && seq_count >= 256u) {
+            const uint32_t tax = (seq_count * 4u) >> 8;
+            if (seq_count > tax + 129u) {
+                huf_tok_size = pivco_encode(tok_st, seq_count, hs + 3u * hstride, seq_count - tax, hs, hs + hstride, PE, lane);
+                tok_huf = huf_tok_size != 0u;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     // ---- assemble: [8 B block header][12 B GLO/GHI header][4 B literal descriptor if RLE][literals]
     //      GLO: [tokens][offsets][extras][pad]   GHI: [sequence words][extras][pad]
     const bool off8 = !GHI && max_off <= 256u && max_off != 0u;
-    const uint32_t sz_tok = GHI ? 4u * seq_count : seq_count;
+    const uint32_t sz_tok = GHI ? 4u * seq_count : (tok_huf ? huf_tok_size : seq_count);
     const uint32_t sz_off = GHI ? 0u : (off8 ? seq_count : 2u * seq_count);
-    const uint32_t lit_sec = use_rle ? rle_size : lit_count;
-    const uint32_t desc = use_rle ? 4u : 0u;
+    const uint32_t lit_sec = lit_huf ? huf_lit_size : (use_rle ? rle_size : lit_count);
+    const uint32_t desc = ((use_rle || lit_huf) ? 4u : 0u) + (tok_huf ? 4u : 0u);  // lit_comp, then tok_comp (A.2 of SURVEY.md)
     uint32_t behind = sz_tok + sz_off + ext_count;
     const uint32_t pad = behind < 32u ? 32u - behind : 0u;
     const uint32_t payload = 12u + desc + lit_sec + behind + pad;
@@ -529,8 +561,26 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         if (lane == 0) sizes[b] = total;
         return;
     }
+    // a wave copy between regions that do not overlap
+    auto wave_copy = [&](uint8_t* dstp, const uint8_t* srcp, uint32_t nbytes) {
+        for (uint32_t o = 0; o < nbytes; o += 1024u) {
+            const uint32_t q = o + 16u * (uint32_t)lane;
+            if (q + 16u <= nbytes) { const v4u t = e_ld128(srcp + q); __builtin_memcpy(dstp + q, &t, 16); }
+            else for (uint32_t k = q; k < nbytes; k++) dstp[k] = srcp[k];
+        }
+    };
+    // the literal section goes behind the descriptors: coded in the scratch (PivCo), coded behind the raw literals (RLE),
+    // or the raw literals themselves
+    if (lit_huf) wave_copy(slot + 20 + desc, hs + 2u * (block_size + 64u), huf_lit_size);
+    else if (use_rle) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        wave_move_down(slot + 20 + desc, lit_out + lit_count + 4u, rle_size, lane);
+    } else if (lit_base != 20u + desc) wave_move_down(slot + 20 + desc, lit_out, lit_count, lane);
     uint8_t* w = slot + 20 + desc + lit_sec;
-    wave_move_down(w, tok_st, sz_tok, lane);
+    if (tok_huf) wave_copy(w, hs + 3u * (block_size + 64u), huf_tok_size);
+    else wave_move_down(w, tok_st, sz_tok, lane);
     w += sz_tok;
     if (off8) {
         for (uint32_t s0 = 0; s0 < seq_count; s0 += 64u) {
@@ -548,10 +598,11 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         uint64_t hv = (GHI ? 2ull : 1ull) | ((uint64_t)payload << 24);  // type 1 = GLO, 2 = GHI
         hv |= (uint64_t)hdr_hash8(hv) << 56;
         __builtin_memcpy(slot, &hv, 8);
-        // n_sequences, n_literals, enc_lit (0 raw / 1 RLE), enc_tok 0, enc_mlen 0, enc_off
-        uint32_t gh[3] = {seq_count, lit_count, (use_rle ? 1u : 0u) | ((uint32_t)(off8 ? 1u : 0u) << 24)};
+        // n_sequences, n_literals, enc_lit (0 raw / 1 RLE / 2 PivCo), enc_tok (0 / 2 PivCo), enc_mlen 0, enc_off
+        uint32_t gh[3] = {seq_count, lit_count, (lit_huf ? 2u : (use_rle ? 1u : 0u)) | (tok_huf ? 2u << 8 : 0u) | ((uint32_t)(off8 ? 1u : 0u) << 24)};
         __builtin_memcpy(slot + 8, gh, 12);
-        if (use_rle) __builtin_memcpy(slot + 20, &rle_size, 4);
+        if (use_rle || lit_huf) __builtin_memcpy(slot + 20, &lit_sec, 4);
+        if (tok_huf) __builtin_memcpy(slot + 20 + ((use_rle || lit_huf) ? 4 : 0), &huf_tok_size, 4);
     }
     uint32_t total = 8u + payload;
     if (with_checksum) {
@@ -582,9 +633,9 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     extern "C" __global__ void __launch_bounds__(64, waves) name(                                                      \
         const uint8_t* __restrict__ src, uint64_t src_size, uint32_t block_size, uint8_t* __restrict__ slots,          \
         uint32_t slot_stride, uint32_t* __restrict__ sizes, uint32_t n_blocks, uint32_t with_checksum, uint32_t depth, \
-        uint32_t sufficient, uint32_t lazy, uint32_t dict_size) {                                                      \
+        uint32_t sufficient, uint32_t lazy, uint32_t dict_size, uint8_t* __restrict__ huf_scratch, uint32_t huf) {     \
         encode_one_block<hb, cwb, ghi>(src, src_size, block_size, slots, slot_stride, sizes, n_blocks, with_checksum,  \
-                                       depth, sufficient, lazy, dict_size);                                            \
+                                       depth, sufficient, lazy, dict_size, huf_scratch, huf);                          \
     }
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l1, 12u, 0u, true, 5)    // level 1
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l2, 12u, 11u, true, 3)   // level 2

@@ -3,17 +3,17 @@
 #ifndef ZXC_ENCODE_LEVELS_H
 #define ZXC_ENCODE_LEVELS_H
 #include <stdint.h>
-typedef struct { int entry; uint32_t depth, sufficient, lazy; } zxc_enc_level_t;
+typedef struct { int entry; uint32_t depth, sufficient, lazy, huf; } zxc_enc_level_t; /* huf: 0 none, 1 PivCo literals, 2 + tokens */
 static inline zxc_enc_level_t zxc_enc_level(int level) {
     static const zxc_enc_level_t t[8] = {
-        {0, 1, 16, 0},    /* (fallback = level 1) */
-        {0, 1, 16, 0},    /* 1: head only, GHI */
-        {1, 3, 18, 0},    /* 2: short chain, GHI */
-        {2, 3, 16, 1},    /* 3 */
-        {2, 6, 18, 2},    /* 4 */
-        {3, 18, 256, 2},  /* 5 */
-        {3, 33, 256, 2},  /* 6 */
-        {3, 66, 256, 2},  /* 7 */
+        {0, 1, 16, 0, 0},    /* (fallback = level 1) */
+        {0, 1, 16, 0, 0},    /* 1: head only, GHI */
+        {1, 3, 18, 0, 0},    /* 2: short chain, GHI */
+        {2, 3, 16, 1, 0},    /* 3 */
+        {2, 6, 18, 2, 0},    /* 4 */
+        {3, 18, 256, 2, 0},  /* 5 */
+        {3, 33, 256, 2, 1},  /* 6: + PivCo-coded literal section */
+        {3, 66, 256, 2, 2},  /* 7: + PivCo-coded token section */
     };
     return t[level < 1 ? 1 : (level > 7 ? 7 : level)];
 }
