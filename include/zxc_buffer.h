@@ -33,6 +33,13 @@ ZXC_EXPORT int64_t zxc_compress(const void* src, const size_t src_size, void* ds
 ZXC_EXPORT int64_t zxc_decompress(const void* src, const size_t src_size, void* dst,
                                   const size_t dst_capacity, const zxc_decompress_opts_t* opts);
 
+/* reference include/zxc_buffer.h:155 / :181 (impl src/lib/zxc_dispatch.c:1129-1185): decode inside ONE caller buffer that
+ * holds the archive flush-right; the bound = decoded size + one block + per-block overhead + trailer + 2112 (or
+ * archive size + one block + 2112, whichever is larger), the reference's formula */
+ZXC_EXPORT size_t zxc_decompress_inplace_bound(const void* src, const size_t src_size);
+ZXC_EXPORT int64_t zxc_decompress_inplace(void* buffer, const size_t buffer_capacity, const size_t comp_size,
+                                          const zxc_decompress_opts_t* opts);
+
 /* reference include/zxc_buffer.h:195 (impl src/lib/zxc_dispatch.c:1203-1225) */
 ZXC_EXPORT uint64_t zxc_get_decompressed_size(const void* src, const size_t src_size);
 

@@ -65,6 +65,28 @@ def test_block_bounds_and_dict_id_match_reference(product, ref):
     assert P.zxc_get_dict_id(b"\0" * 16, 16) == 0 and P.zxc_get_dict_id(b"", 0) == 0
 
 
+def test_inplace_bound_matches_reference(product, ref, manifest):
+    """zxc_decompress_inplace_bound (src/lib/zxc_dispatch.c:1129-1145) is host arithmetic over header + footer: the same
+    number as the reference for every golden archive, 0 for garbage; argument errors of zxc_decompress_inplace alike."""
+    P, R = C.CDLL(product.lib_path()), ref.lib
+    for L in (P, R):
+        L.zxc_decompress_inplace_bound.restype = C.c_size_t
+        L.zxc_decompress_inplace_bound.argtypes = [C.c_char_p, C.c_size_t]
+        L.zxc_decompress_inplace.restype = C.c_int64
+        L.zxc_decompress_inplace.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    for name in manifest["synth"]:
+        b = read(f"synth/{name}.zxc")
+        assert P.zxc_decompress_inplace_bound(b, len(b)) == R.zxc_decompress_inplace_bound(b, len(b)) > 0, name
+    for f in manifest["conformance_invalid"]:
+        b = read(f"conformance/invalid/{f}")
+        assert P.zxc_decompress_inplace_bound(b, len(b)) == R.zxc_decompress_inplace_bound(b, len(b)), f
+    b = read("synth/mixed_384k_l3_b64k.zxc")
+    buf = C.create_string_buffer(len(b) + 100)
+    C.memmove(C.addressof(buf) + 100, b, len(b))
+    assert P.zxc_decompress_inplace(buf, len(b) + 100, len(b), None) == R.zxc_decompress_inplace(buf, len(b) + 100, len(b), None) == -2
+    assert P.zxc_decompress_inplace(buf, 10, len(b), None) == R.zxc_decompress_inplace(buf, 10, len(b), None) == -12
+
+
 def test_zxd_container_helpers_match_reference(product, ref):
     """zxc_dict_id / zxc_dict_load / zxc_dict_save / zxc_dict_get_id / zxc_dict_huf (reference src/lib/zxc_dict.c:35-205):
     same ids, same bytes, same error codes as the unmodified reference on the conformance .zxd files and on damaged ones."""

@@ -143,6 +143,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     constexpr uint32_t HSIZE = 1u << HB;
     constexpr uint32_t CW = CWB ? (1u << CWB) : 1u;
     constexpr uint32_t CWM = CW - 1u;
+    constexpr bool DEEP = CWB >= 13u;  // the levels 5-7 entry: the only one that carries the PivCo section encoder
     __shared__ __attribute__((aligned(16))) uint16_t ht[HSIZE];  // head: low 16 bits of the most recent position with this hash
     __shared__ uint16_t chain[CW];     // chain[q & CWM]: distance from q to the previous position with q's hash (0: none)
     const int lane = threadIdx.x;
@@ -159,7 +160,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     const uint32_t n = D + nblk;
     uint8_t* slot = slots + (uint64_t)b * slot_stride;
     // literals are gathered behind room for the widest descriptor set (levels 6-7: lit_comp + tok_comp) and slid down at the end
-    const uint32_t lit_base = (HB >= 14u && huf != 0u) ? 28u : 20u;
+    const uint32_t lit_base = (DEEP && huf != 0u) ? 28u : 20u;
     uint8_t* lit_out = slot + lit_base;
     const uint32_t max_seq = block_size / 5u + 16u;
     uint8_t* tok_st = slot + block_size + 64u;                // GLO: 1 byte per sequence; GHI: one 32-bit word
@@ -499,9 +500,9 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     bool lit_huf = false, tok_huf = false;
     uint32_t huf_lit_size = 0, huf_tok_size = 0;
     uint8_t* hs = nullptr;
-    if (HB >= 14u && !GHI && huf != 0u && !overflow) {
+    if (DEEP && !GHI && huf != 0u && !overflow) {
         PivEnc& PE = *reinterpret_cast<PivEnc*>(ht);  // the match finder's tables are dead now
-        static_assert(HB < 14u || sizeof(PivEnc) <= (sizeof(uint16_t) << (HB < 14u ? 14u : HB)), "PivEnc must fit the head table");
+        static_assert(!DEEP || sizeof(PivEnc) <= sizeof(uint16_t) * HSIZE, "PivEnc must fit the head table");
         const uint32_t hstride = block_size + 64u;
         hs = huf_scratch + (uint64_t)b * 4u * hstride;  // [level buffer A | level buffer B | literal section | token section]
         __builtin_amdgcn_s_waitcnt(0);
@@ -640,7 +641,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l1, 12u, 0u, true, 5)    // level 1
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l2, 12u, 11u, true, 3)   // level 2
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l34, 13u, 12u, false, 2) // levels 3-4
-ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l57, 14u, 14u, false, 1) // levels 5-7
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l57, 13u, 14u, false, 1) // levels 5-7
 
 // [dict | block b] images for the dictionary path: work + b * (block_size + dict_size)
 extern "C" __global__ void __launch_bounds__(64)

@@ -55,8 +55,6 @@ static struct {
     /* launch-order buffers ([128 u32 histogram + cursors | order[n]]), one per stream seen: launches on
      * one stream are ordered, so a stream's buffer is free again when its next launch is enqueued */
     struct { void* stream; uint32_t* buf; size_t cap; int used; } ord[ZXC_ORDER_STREAMS];
-    uint8_t* huf;      /* PivCo encoder scratch (levels 6-7), grown on demand */
-    size_t huf_bytes;
 } g_dev[ZXC_MAX_DEVICES];
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 
@@ -248,26 +246,21 @@ static int encode_launch(const void* d_src, uint64_t src_size, uint32_t block_si
     }
     const zxc_enc_level_t lp = zxc_enc_level(level);
     uint8_t* huf_scratch = NULL;
-    if (lp.huf) {  // levels 6-7: level buffers + coded sections of the PivCo encoder, 4 x (block_size + 64) per block
-        const int dev = current_device();
+    if (lp.huf) {
+        // levels 6-7: level buffers + coded sections of the PivCo encoder, 4 x (block_size + 64) per block. Stream-ordered
+        // allocation: it belongs to this launch alone (concurrent launches on other streams get their own) and is given
+        // back to the device pool right behind the kernel.
         const size_t need = (size_t)nb * 4u * ((size_t)block_size + 64u);
-        pthread_mutex_lock(&g_lock);
-        if (g_dev[dev].huf_bytes < need) {
-            if (g_dev[dev].huf) (void)hipFree(g_dev[dev].huf);  // (hipFree synchronises: no launch is still using it)
-            g_dev[dev].huf = NULL;
-            g_dev[dev].huf_bytes = 0;
-            if (hipMalloc((void**)&g_dev[dev].huf, need) == hipSuccess) g_dev[dev].huf_bytes = need;
-        }
-        huf_scratch = g_dev[dev].huf;
-        pthread_mutex_unlock(&g_lock);
-        if (!huf_scratch) return ZXC_ERROR_MEMORY;
+        if (hipMallocAsync((void**)&huf_scratch, need, (hipStream_t)stream) != hipSuccess || !huf_scratch) return ZXC_ERROR_MEMORY;
     }
     auto kern = lp.entry == 0 ? zxc_encode_blocks_kernel_l1 : lp.entry == 1 ? zxc_encode_blocks_kernel_l2
               : lp.entry == 2 ? zxc_encode_blocks_kernel_l34 : zxc_encode_blocks_kernel_l57;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64), 0, (hipStream_t)stream, in, src_size, block_size,
                        (uint8_t*)d_slots, zxc_mi355x_encode_slot_stride(block_size), d_sizes, nb, with_checksum ? 1u : 0u,
                        lp.depth, lp.sufficient, lp.lazy, dict_size, huf_scratch, lp.huf);
-    return hipGetLastError() == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
+    const hipError_t lerr = hipGetLastError();
+    if (huf_scratch) (void)hipFreeAsync(huf_scratch, (hipStream_t)stream);
+    return lerr == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
 }
 
 int zxc_mi355x_encode_blocks_device(const void* d_src, uint64_t src_size, uint32_t block_size, int level,

@@ -488,6 +488,51 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
     return (int64_t)total;
 }
 
+/* ------------------------------------------------ in-place decode (one buffer) */
+/* reference include/zxc_buffer.h:155-181, impl src/lib/zxc_dispatch.c:1056-1185: the archive sits flush-right in the
+ * buffer, the output grows from its start; the bound keeps the write cursor behind the read cursor. Here blocks are
+ * uploaded batch by batch before their output comes back, and a batch's output ends where the sequential decoder's
+ * would, so the same bound holds. */
+static int inplace_probe(const uint8_t* comp, size_t comp_size, uint64_t* dsize, uint64_t* margin, uint64_t* floor_) {
+    if (rd32(comp) != MAGIC) return ZXC_ERROR_BAD_MAGIC;
+    uint32_t bs, did;
+    int ck;
+    if (read_file_header(comp, comp_size, &bs, &ck, &did) != ZXC_OK) return ZXC_ERROR_BAD_HEADER;
+    const uint64_t d = rd64(comp + comp_size - ZXC_FILE_FOOTER_SIZE);
+    const uint64_t need = d / bs + (d % bs != 0);
+    if (need > (uint64_t)(comp_size / BLK_HDR)) return ZXC_ERROR_CORRUPT_DATA;
+    const uint64_t nblocks = (d + bs - 1) / bs;
+    const uint64_t per_block = BLK_HDR + (ck ? 4u : 0u);
+    const uint64_t trailing = BLK_HDR + (BLK_HDR + nblocks * 4u) + ZXC_FILE_FOOTER_SIZE;
+    *dsize = d;
+    *margin = (uint64_t)bs + nblocks * per_block + trailing + TAIL_PAD;
+    *floor_ = (uint64_t)bs + TAIL_PAD;
+    return ZXC_OK;
+}
+size_t zxc_decompress_inplace_bound(const void* src, const size_t src_size) {
+    if (!src || src_size < ZXC_FILE_HEADER_SIZE + ZXC_FILE_FOOTER_SIZE) return 0;
+    uint64_t dsize = 0, margin = 0, fl = 0;
+    if (inplace_probe((const uint8_t*)src, src_size, &dsize, &margin, &fl) != ZXC_OK) return 0;
+    if (margin > (uint64_t)SIZE_MAX || dsize > (uint64_t)SIZE_MAX - margin) return 0;
+    if (fl > (uint64_t)SIZE_MAX - (uint64_t)src_size) return 0;
+    const uint64_t a = dsize + margin, b = (uint64_t)src_size + fl;
+    return (size_t)(a > b ? a : b);
+}
+int64_t zxc_decompress_inplace(void* buffer, const size_t buffer_capacity, const size_t comp_size,
+                               const zxc_decompress_opts_t* opts) {
+    if (!buffer || comp_size < ZXC_FILE_HEADER_SIZE + ZXC_FILE_FOOTER_SIZE || comp_size > buffer_capacity)
+        return ZXC_ERROR_NULL_INPUT;
+    uint8_t* buf = (uint8_t*)buffer;
+    const uint8_t* comp = buf + (buffer_capacity - comp_size);
+    uint64_t dsize = 0, margin = 0, fl = 0;
+    const int rc = inplace_probe(comp, comp_size, &dsize, &margin, &fl);
+    if (rc != ZXC_OK) return rc;
+    if (dsize > (uint64_t)buffer_capacity || (uint64_t)buffer_capacity - dsize < margin) return ZXC_ERROR_DST_TOO_SMALL;
+    if ((uint64_t)(buffer_capacity - comp_size) < fl) return ZXC_ERROR_DST_TOO_SMALL;
+    if (dsize == 0) return 0;
+    return zxc_decompress(comp, comp_size, buf, buffer_capacity, opts);
+}
+
 /* ------------------------------------------------------------ zxc_compress */
 static void wr64(uint8_t* p, uint64_t v) {
     wr32(p, (uint32_t)v);
