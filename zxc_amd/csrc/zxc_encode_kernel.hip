@@ -641,7 +641,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l1, 12u, 0u, true, 5)    // level 1
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l2, 12u, 11u, true, 3)   // level 2
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l34, 13u, 12u, false, 2) // levels 3-4
-ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l57, 13u, 14u, false, 1) // levels 5-7
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l57, 14u, 14u, false, 1) // levels 5-7
 
 // [dict | block b] images for the dictionary path: work + b * (block_size + dict_size)
 extern "C" __global__ void __launch_bounds__(64)
