@@ -428,7 +428,7 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
             const uint64_t phys = (uint64_t)BLK_HDR + csz + (file_ck ? 4u : 0u);
             jobs[n].comp_off = ip - span0;
             /* the wrapper sees "all remaining bytes"; any size >= the physical block is equivalent */
-            jobs[n].comp_size = (uint32_t)(phys < rem ? phys : rem);
+            { const uint64_t cs = phys < rem ? phys : rem; jobs[n].comp_size = cs > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cs; }
             jobs[n].out_off = (uint64_t)n * block_size;
             jobs[n].out_len = block_size;
             n++;
