@@ -25,6 +25,18 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     stream = torch.cuda.current_stream().cuda_stream
     def step(): zxc_amd.decode_blocks_device(d_comp.data_ptr(), d_jobs.data_ptr(), n, d_out.data_ptr(), d_st.data_ptr(), 65536, False, stream)
     step(); step(); torch.cuda.synchronize()
+    if os.environ.get("AB_PHASES"):  # library built with -DEXP_PHASES: per-phase shader clocks in each block's first 32 bytes
+        ph = d_out[:n * 65536].view(-1, 65536)[:, :64].cpu().numpy().view(np.uint32).astype(np.float64)
+        ph = ph[(ph < 5e7).all(axis=1)]  # RAW blocks never reach the sequence loop: their bytes are data
+        names = ["varints: fast path / none", "long literals", "literal wait + far requests", "rounds: 16-byte group steps", "rounds: sparse finish", "flush", "loop tail",
+                 "literal groups / giant", "varints: general path", "scans + bounds", "next tokens requested", "", "", "deps (registers only)", "rounds: byte loops", "rounds: whole-wave copies"]
+        cnt = ph[:, 11:13].copy(); ph[:, 11:13] = 0; ph = ph[:, :16]
+        tot = ph.sum()
+        for i, nm in enumerate(names):
+            if nm: print(f"  {nm:26s} {100 * ph[:, i].sum() / tot:5.1f} %   mean {ph[:, i].mean():9.0f} clk/block")
+        print(f"  total mean {ph.sum(axis=1).mean():.0f} clk/block over {ph.shape[0]} blocks; batches/block {cnt[:, 0].mean():.1f}, "
+              f"rounds/block {cnt[:, 1].mean():.1f}", flush=True)
+        sys.exit(0)
     ok = bool((d_st == 65536).all().item()) and torch.equal(d_out[:n * 65536], d_want)
     best = 1e9
     for _ in range(3):

@@ -68,7 +68,8 @@ typedef v4u __attribute__((aligned(1))) v4u_unaligned;
 #define LIT_LOOP2 1      // literal groups beyond the third: two per step, requested unconditionally (0: one conditional load per step)
 #endif
 #ifndef FAR_EARLY
-#define FAR_EARLY 0      // 1: far-source groups requested unconditionally, before the literal wait (A/B)
+#define FAR_EARLY 0      // far-source groups: 0 requested after the literal wait; 1 by every lane, unconditionally, before it (A/B: -6.5 %);
+                         // 2 by the lanes that need them, before the dependency analysis (A/B: -4.5 %)
 #endif
 #define BYTEWISE_MAX 32u // short-period overlapping matches up to this long: lane-local byte loop
 
@@ -90,8 +91,10 @@ typedef v4u __attribute__((aligned(1))) v4u_unaligned;
 
 #ifdef EXP_PHASES  // experiment only: per-phase shader-clock totals of each block, written over the block's first 32 output bytes
 #define PH(i) do { const uint64_t t_ = __builtin_readcyclecounter(); ph[i] += (uint32_t)(t_ - ph_last); ph_last = t_; } while (0)
+#define PHC(i) do { ph[i] += 1u; } while (0)
 #else
 #define PH(i) do { } while (0)
+#define PHC(i) do { } while (0)
 #endif
 
 struct __attribute__((aligned(16))) WaveLds {
@@ -136,9 +139,14 @@ __device__ __forceinline__ uint32_t wave_min(uint32_t v) {
     }
     return v;
 }
-// LDS traffic between lanes of the one wave: order it, no s_barrier needed
+// LDS traffic between lanes of the one wave. One wave's DS instructions execute in program order, so a read issued
+// after another lane's write sees it: only the COMPILER must keep the order (wavefront-scope fence: no instruction,
+// where a workgroup-scope one drains the LDS queue with s_waitcnt lgkmcnt(0), ~10 times per batch).
+#ifndef LDS_FENCE_SCOPE
+#define LDS_FENCE_SCOPE "wavefront"
+#endif
 __device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, LDS_FENCE_SCOPE);
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -424,17 +432,20 @@ __device__ __forceinline__ uint32_t lanes_le(uint32_t sorted, uint32_t x) {
     return c + ((c == 63u && t63 <= x) ? 1u : 0u);
 }
 
-// Token and offset of sequence s, undecoded (GHI: the 32-bit word; GLO: token byte, offset - 1).
+// Token and offset of sequence s, undecoded (GHI: the 32-bit word; GLO: token byte, offset - 1). Requested by every lane,
+// beyond the last sequence too (a conditional load would be waited for on the spot, and zero-initialising its register
+// makes the compiler drain every older vector-memory access first): such lanes read the last sequence's bytes and the
+// consumer masks them (n_seq >= 1 here, or the streams are empty and nothing is read).
 template <bool GHI>
 __device__ __forceinline__ void load_seq_raw(const LzStreams& S, uint32_t s, uint32_t& raw_t, uint32_t& raw_o) {
     raw_t = 0;
     raw_o = 0;
-    if (s < S.n_seq) {
-        if (GHI) raw_t = ld32(S.tok + 4ull * s);
-        else {
-            raw_t = ld8(S.tok + s);
-            raw_o = S.off8 ? ld8(S.offs + s) : ld16(S.offs + 2ull * s);
-        }
+    if (S.n_seq == 0u) return;  // wave-uniform
+    const uint32_t c = s < S.n_seq ? s : S.n_seq - 1u;
+    if (GHI) raw_t = ld32(S.tok + 4ull * c);
+    else {
+        raw_t = ld8(S.tok + c);
+        raw_o = S.off8 ? ld8(S.offs + c) : ld16(S.offs + 2ull * c);
     }
 }
 
@@ -460,7 +471,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
     uint32_t p = 0, lp = 0, cur = 0, dead = 0, seq_base = 0;
     uint32_t z_end = RING_BYTES;
 #ifdef EXP_PHASES
-    uint32_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t ph_last = __builtin_readcyclecounter();
 #endif
 
@@ -474,14 +485,19 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
 
     uint32_t raw_t, raw_o;
     load_seq_raw<GHI>(S, (uint32_t)lane, raw_t, raw_o);
-    uint32_t xw0 = (uint32_t)lane < S.ext_size ? ld8(S.ext + lane) : 0u;
-    uint32_t xw1 = 64u + (uint32_t)lane < S.ext_size ? ld8(S.ext + 64u + lane) : 0u;
+    // (requested by every lane, clamped to the stream's last byte — or the byte in front of an empty stream: only bytes
+    // below the stream's end are ever looked at)
+    const int32_t ext_last = (int32_t)S.ext_size - 1;
+    uint32_t xw0 = ld8(S.ext + (lane < ext_last ? lane : ext_last));
+    uint32_t xw1 = ld8(S.ext + (64 + lane < ext_last ? 64 + lane : ext_last));
+    __builtin_amdgcn_s_waitcnt(0);  // (once per block: the loop is entered with nothing on the compiler's scoreboard, see the flush)
 
     while (seq_base < n_total) {
         const uint32_t s = seq_base + (uint32_t)lane;
         const bool real = s < S.n_seq;
         const bool valid = s < n_total;
-        // (raw_t / raw_o were requested while the previous batch was being copied; they are 0 beyond n_seq)
+        // (raw_t / raw_o were requested while the previous batch was being copied; beyond n_seq they hold the last sequence's)
+        if (!real) { raw_t = 0; raw_o = 0; }
         uint32_t ll, ml, off;
         bool escL, escM;
         if (GHI) {
@@ -528,6 +544,10 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             }
         }
         ml += real ? 5u : 0u;
+#ifdef EXP_PHASES
+        PHC(11);
+        if (parsed && !fast_vi) PH(8); else PH(0);
+#endif
 
         // cursors: inclusive scans of (ll+ml) and ll
         uint32_t len = ll + ml;
@@ -559,6 +579,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             if (e <= k) return __shfl(err, (int)e);  // first failing sequence in stream order
         }
 
+        PH(9);
         // the next batch starts at sequence seq_base + max(k, 1): request its tokens and offsets now
         uint32_t nraw_t, nraw_o;
         load_seq_raw<GHI>(S, seq_base + (k ? k : 1u) + (uint32_t)lane, nraw_t, nraw_o);
@@ -571,11 +592,13 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             else if (kbad < used) { dead = 1; cur = S.ext_size; }
             else cur = uni(L.vpos[used]);
         }
-        const uint32_t nxw0 = cur + (uint32_t)lane < S.ext_size ? ld8(S.ext + cur + lane) : 0u;
-        const uint32_t nxw1 = cur + 64u + (uint32_t)lane < S.ext_size ? ld8(S.ext + cur + 64u + lane) : 0u;
-        PH(0);
+        const int32_t xi0 = (int32_t)(cur + (uint32_t)lane), xi1 = xi0 + 64;
+        const uint32_t nxw0 = ld8(S.ext + (xi0 < ext_last ? xi0 : ext_last));
+        const uint32_t nxw1 = ld8(S.ext + (xi1 < ext_last ? xi1 : ext_last));
+        PH(10);
         if (k == 0u) {
             // ---- one giant sequence (> TILE_MAX bytes): the whole wave walks it in pieces (plain stores)
+            __builtin_amdgcn_s_waitcnt(0);  // (nothing stays on the compiler's scoreboard across the loop edge: see the flush below)
             const uint32_t gll = uni(ll), gml = uni(ml), goff = uni(off);
             uint32_t donel = 0;
             while (donel < gll) {
@@ -636,6 +659,26 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             bool pending = mine && ml != 0u;
             uint64_t need = 0;
             uint32_t qsrc = qa;  // where the copy reads from (qa unless redirected)
+            // A match lands on ITS destination's dword grid like a literal run: group g = 16 bytes at
+            // (M & ~3) + 16 g, from source position qsrc - (M & 3) + 16 g.
+            const uint32_t ma = M & 3u;
+            const uint32_t me = ma + ml;
+            const uint32_t mg = M - ma;          // grid origin (4-aligned output position)
+            const bool overlap = off < ml;
+#if FAR_EARLY == 2
+            // Sources older than the ring come back from the block's own output through L2 (~2 K clocks under load).
+            // Such a source ends at least 350 bytes before the batch (ring_lo <= p - 497, ml <= MATCH_MED): the lane
+            // depends on nothing in this batch and is not redirected, and its bytes were flushed by an earlier batch
+            // (one wave's stores and loads reach L2 in program order). Its first two groups are requested HERE, behind
+            // the literal loads, so the round trip runs under the whole dependency analysis below.
+            const bool pf = pending && !fromdict && ml <= MATCH_MED && (!overlap || off >= 16u) && qa < ring_lo && qa >= 4u &&
+                            (qa - ma) + 32u <= O.out_pad;
+            v4u fr0 = {0, 0, 0, 0}, fr1 = {0, 0, 0, 0};
+            if (pf) {
+                fr0 = __builtin_nontemporal_load((const v4u_unaligned*)(O.dst + (qa - ma)));
+                if (me > 16u) fr1 = __builtin_nontemporal_load((const v4u_unaligned*)(O.dst + (qa - ma) + 16u));
+            }
+#endif
             {
                 // all lanes run the same bpermute sequence; only lanes reaching into the batch use it
                 const uint32_t ja = lanes_le(Es, fromdict ? 0u : qa);     // first lane with E > qa
@@ -660,13 +703,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                     }
                 }
             }
-            // A match lands on ITS destination's dword grid the same way: group g = 16 bytes at
-            // (M & ~3) + 16 g, from source position qsrc - (M & 3) + 16 g.
-            const uint32_t ma = M & 3u;
-            const uint32_t me = ma + ml;
-            const uint32_t mg = M - ma;          // grid origin (4-aligned output position)
-            const uint32_t sg = qsrc - ma;       // its source (may be "negative" by up to 3 for qsrc < 3: only masked-off bytes)
-            const bool overlap = off < ml;
+            const uint32_t sg = qsrc - ma;       // the match's source on the destination's dword grid (may be "negative" by up to 3 for qsrc < 3: only masked-off bytes)
             // lane-per-sequence in 16-byte groups works whenever a group's source is complete before
             // the group is put: no overlap at all, or a period of at least one group (+ grid phase).
             const bool farsrc = qsrc < ring_lo;
@@ -678,9 +715,14 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             // lane depends on nothing in this batch, so its first two groups are requested here: the literal
             // loads above are older (VMEM returns in order), so waiting for them below does not wait for
             // these, and the literal puts run under the round trip.
+#if FAR_EARLY != 2
             const bool pf = pending && need == 0ull && stepable && farsrc && sg + 32u <= O.out_pad;
             v4u fr0 = {0, 0, 0, 0}, fr1 = {0, 0, 0, 0};
-#if FAR_EARLY
+#endif
+#if FAR_EARLY == 2
+            __builtin_amdgcn_s_waitcnt(0);  // literal data and the far groups (also: every flush store has landed)
+            far_waited = true;
+#elif FAR_EARLY
             // Both groups are requested by EVERY lane (lanes without a far source read the block's first 32
             // bytes: one cache line, no divergence), right behind the literal loads and without waiting for
             // anything: a wave's own stores and loads reach L2 in program order, so the flush stores that wrote
@@ -694,6 +736,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
 #else
             // (unconditional wait: the literal data is needed next anyway, and with every older access known to
             // be complete on both paths the compiler does not force these loads to finish before the literal puts)
+            PH(13);
             __builtin_amdgcn_s_waitcnt(0);  // also: the flush stores that wrote those bytes have landed
             far_waited = true;
             if (pf) {
@@ -782,6 +825,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                         ring_or_group(L, mg + go, d);
                     }
                 }
+                PH(3);
                 // short period (off < 16, off < ml <= 32): byte loop over the period [M-off, M)
                 const bool sb = can && bytewise;
                 if (__ballot(sb)) {
@@ -796,6 +840,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                         }
                     }
                 }
+                PH(14);
                 // long: the whole wave copies one match at a time
                 uint64_t lm = __ballot(can && is_long);
                 if (lm) wave_lds_fence();
@@ -808,9 +853,8 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                 }
                 if (can) pending = false;
                 wave_lds_fence();
-#ifdef EXP_PHASES
-                if (round == 0u) PH(3); else PH(4);
-#endif
+                PH(15);
+                PHC(12);
                 // Few sequences left (the typical batch has ~4 dependent ones spread over 1-2 more rounds):
                 // finish them one by one in stream order with the whole wave, a byte per lane. In order,
                 // every source is complete by construction, and one such copy costs a small fraction of
@@ -854,10 +898,26 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             }
             p = tile_end;
             lp = (uint32_t)__builtin_amdgcn_readlane((int)(lst + ll), (int)(k - 1u));
+            // Every load of this batch has been consumed by now, but some only under a condition, and the compiler
+            // keeps those on its scoreboard: the first register reuse in the next batch would then wait for everything
+            // older, i.e. for the flush stores below (~3 K clocks per batch, measured). Waiting here costs nothing
+            // and leaves only the stores outstanding across the loop edge.
+            __builtin_amdgcn_s_waitcnt(0);
             flush_to(L, O, p, lane);
             PH(5);
         }
 
+#ifdef EXP_EXTRA_VALU  // experiment only: EXP_EXTRA_VALU independent VALU instructions per batch (is the kernel VALU-bound?)
+        {
+            uint32_t dummy = (uint32_t)lane;
+#pragma unroll
+            for (int i = 0; i < EXP_EXTRA_VALU; i++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(dummy));
+            asm volatile("" ::"v"(dummy));
+        }
+#endif
+#ifdef EXP_EXTRA_SLEEP  // experiment only: the wave sleeps 64 x EXP_EXTRA_SLEEP clocks per batch (is it latency-bound?)
+        __builtin_amdgcn_s_sleep(EXP_EXTRA_SLEEP);
+#endif
         seq_base += k;
         raw_t = nraw_t;
         raw_o = nraw_o;
@@ -868,8 +928,12 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
     }
 #ifdef EXP_PHASES
     __builtin_amdgcn_s_waitcnt(0);
-    if (lane < 8) ((uint32_t*)dst)[lane] = ph[0] * (lane == 0) + ph[1] * (lane == 1) + ph[2] * (lane == 2) + ph[3] * (lane == 3) +
-                                           ph[4] * (lane == 4) + ph[5] * (lane == 5) + ph[6] * (lane == 6) + ph[7] * (lane == 7);
+    if (lane < 16) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) v = (lane == i) ? ph[i] : v;
+        ((uint32_t*)dst)[lane] = v;
+    }
     return (int)p;
 #endif
     // the last chunk may be partial: it only lives in the ring so far
