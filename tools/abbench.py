@@ -25,6 +25,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     stream = torch.cuda.current_stream().cuda_stream
     def step(): zxc_amd.decode_blocks_device(d_comp.data_ptr(), d_jobs.data_ptr(), n, d_out.data_ptr(), d_st.data_ptr(), 65536, False, stream)
     step(); step(); torch.cuda.synchronize()
+    if os.environ.get("AB_PIVPROF"):  # library built with -DEXP_PIV_PROF: clock split of the PivCo section decoder in output bytes 64..127
+        pr = d_out[:n * 65536].view(-1, 65536)[:, 64:128].cpu().numpy().view(np.uint32).astype(np.float64)
+        pr = pr[(pr[:, :8] < 5e7).all(axis=1) & (pr[:, 6] > 0)]
+        names = ["group set-up + small nodes", "medium nodes (work items)", "big flat: code table", "big flat: unpack", "big bitmap: set-up",
+                 "big bitmap: words", "header + tree + pass 1", "level end (store drain)"]
+        for i, nm in enumerate(names): print(f"  {nm:28s} mean {pr[:, i].mean():9.0f} clk/block")
+        print(f"  per block: big flat nodes {pr[:, 8].mean():.1f} ({pr[:, 9].mean():.0f} steps), big bitmap nodes {pr[:, 10].mean():.1f} "
+              f"({pr[:, 11].mean():.0f} words), medium nodes {pr[:, 12].mean():.1f}; blocks {pr.shape[0]}", flush=True)
+        sys.exit(0)
     if os.environ.get("AB_PHASES"):  # library built with -DEXP_PHASES: per-phase shader clocks in each block's first 32 bytes
         ph = d_out[:n * 65536].view(-1, 65536)[:, :64].cpu().numpy().view(np.uint32).astype(np.float64)
         ph = ph[(ph < 5e7).all(axis=1)]  # RAW blocks never reach the sequence loop: their bytes are data

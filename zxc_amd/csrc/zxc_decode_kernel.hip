@@ -1172,6 +1172,9 @@ __device__ __forceinline__ void decode_one_block(const uint8_t* __restrict__ com
     WaveLds& L = lds.w;
     const int lane = threadIdx.x;
     if (blockIdx.x >= n_jobs) return;
+#ifdef EXP_PIV_PROF
+    if (lane < 16) g_piv_prof[lane] = lane == 15 ? (uint32_t)__builtin_readcyclecounter() : 0u;
+#endif
     // heaviest blocks first when the launch is long enough for the tail to matter (see zxc_order_* below)
     const uint32_t b = order ? uni(order[blockIdx.x]) : blockIdx.x;
 #ifdef EXP_TIMES  // experiment only: status = start (hi 16) and duration (lo 16) in units of 32 ticks of the 100 MHz clock
@@ -1229,6 +1232,10 @@ __device__ __forceinline__ void decode_one_block(const uint8_t* __restrict__ com
     __builtin_amdgcn_s_waitcnt(0);
     const uint64_t t_end = wall_clock64();
     rc = (int)((((uint32_t)(t_start >> 5) & 0xFFFFu) << 16) | (uint32_t)(((t_end - t_start) >> 5) & 0xFFFFu));
+#endif
+#ifdef EXP_PIV_PROF
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane < 16 && out_len >= 128u) ((uint32_t*)(dst + 64))[lane] = g_piv_prof[lane];
 #endif
     if (lane == 0) status[b] = rc;
 }

@@ -640,7 +640,12 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     }
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l1, 12u, 0u, true, 5)    // level 1
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l2, 12u, 11u, true, 3)   // level 2
-ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l34, 13u, 12u, false, 2) // levels 3-4
+#ifndef ENC_L34_HB  // (A/B: tools/build_enc_variant.sh)
+#define ENC_L34_HB 13u
+#define ENC_L34_CWB 12u
+#define ENC_L34_WAVES 2
+#endif
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l34, ENC_L34_HB, ENC_L34_CWB, false, ENC_L34_WAVES) // levels 3-4
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l57, 14u, 14u, false, 1) // levels 5-7
 
 // [dict | block b] images for the dictionary path: work + b * (block_size + dict_size)
