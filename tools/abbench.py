@@ -30,9 +30,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         pr = pr[(pr[:, :8] < 5e7).all(axis=1) & (pr[:, 6] > 0)]
         names = ["group set-up + small nodes", "medium nodes (work items)", "big flat: code table", "big flat: unpack", "big bitmap: set-up",
                  "big bitmap: words", "header + tree + pass 1", "level end (store drain)"]
-        for i, nm in enumerate(names): print(f"  {nm:28s} mean {pr[:, i].mean():9.0f} clk/block")
+        names[1] = ""; names[6] = "sequence offsets"
+        for i, nm in enumerate(names):
+            if nm: print(f"  {nm:28s} mean {pr[:, i].mean():9.0f} clk/block")
+        for i, nm in ((12, "header + code lengths"), (13, "levels + flat roots"), (14, "pass 1 (sizes, popcounts)")): print(f"  {nm:28s} mean {pr[:, i].mean():9.0f} clk/block")
         print(f"  per block: big flat nodes {pr[:, 8].mean():.1f} ({pr[:, 9].mean():.0f} steps), big bitmap nodes {pr[:, 10].mean():.1f} "
-              f"({pr[:, 11].mean():.0f} words), medium nodes {pr[:, 12].mean():.1f}; blocks {pr.shape[0]}", flush=True)
+              f"({pr[:, 11].mean():.0f} words), medium nodes {0:.1f}; blocks {pr.shape[0]}", flush=True)
         sys.exit(0)
     if os.environ.get("AB_PHASES"):  # library built with -DEXP_PHASES: per-phase shader clocks in each block's first 32 bytes
         ph = d_out[:n * 65536].view(-1, 65536)[:, :64].cpu().numpy().view(np.uint32).astype(np.float64)
