@@ -124,13 +124,14 @@ def pmc_traffic(args, tiles):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and
     WRITE_SIZE collected in separate --pmc runs, profiles/<round>_summary.json). NOT measured in this run: a
     constant that is only reported for the configuration the profile was taken on; otherwise null."""
-    try:
-        summ = json.load(open(os.path.join(ROOT, "profiles", "r2_summary.json")))
-        if summ.get("workload") == dict(tiles=tiles, level=args.level, block_size=args.block_size):
-            return summ["hbm_traffic_bytes_per_launch"]["total"]
-    except Exception:
-        pass
-    return None
+    for name in ("r2_summary.json", "r2l7_summary.json"):  # the default workload, the level-7 workload (configs[4])
+        try:
+            summ = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if summ.get("workload") == dict(tiles=tiles, level=args.level, block_size=args.block_size):
+                return summ["hbm_traffic_bytes_per_launch"]["total"], f"profiles/{name}"
+        except Exception:
+            pass
+    return None, None
 
 
 def cpu_baseline(comp, total, budget_s=12.0):
@@ -468,7 +469,7 @@ def main():
         cfg = "configs[4]" if args.level == 7 else "configs[1]" if args.level == 3 else f"configs[1] at level {args.level}"
         if world > 1:
             cfg = f"configs[3] ({world * args.tiles * 211943424 / 2**30:.1f} GiB corpus over {world} GPUs)"
-        traffic = pmc_traffic(args, args.tiles)
+        traffic, traffic_file = pmc_traffic(args, args.tiles)
         line = {
             "metric": f"seekable decode GB/s (level {args.level}, {bs >> 10} KiB independent blocks, HBM-resident in/out"
                       + (", per-block checksums verified on the device)" if args.checksum else ")"),
@@ -484,7 +485,7 @@ def main():
                        "parallelism": f"seek-table block range x{world}, no collectives on the data path", "prep": prep},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": "profiles/r2_summary.json (rocprofv3 PMC passes of this command), not this run"
+                         "traffic_source": f"{traffic_file} (rocprofv3 PMC passes of this command), not this run"
                                            if traffic else None,
                          "kernel": "zxc_decode_blocks_kernel", "avg_launch_ms": round(avg_kernel_s * 1e3, 4),
                          "algorithmic_bytes_per_launch": algo_bytes},
