@@ -78,7 +78,9 @@ ZXC_EXPORT int zxc_mi355x_decode_blocks_dict_device(const void* d_comp, const zx
  * made by zxc_compress (src/lib/zxc_dispatch.c:734-780). Block i of the source
  * (d_src + i*block_size) becomes one complete v8 block (8-byte header + payload, GLO or RAW) at
  * d_slots + i*zxc_mi355x_encode_slot_stride(block_size); its size lands in d_sizes[i]
- * (= the seek-table entry; with_checksum appends the 4-byte rapidhash trailer). Asynchronous on `stream`. */
+ * (= the seek-table entry; with_checksum appends the 4-byte rapidhash trailer). Asynchronous on `stream`.
+ * d_src must be READABLE up to src_size + 32 (the match finder compares 16 bytes at a time and clamps lengths to the
+ * block afterwards; the bytes themselves are never used). */
 ZXC_EXPORT uint32_t zxc_mi355x_encode_slot_stride(uint32_t block_size);
 ZXC_EXPORT int zxc_mi355x_encode_blocks_device(const void* d_src, uint64_t src_size, uint32_t block_size,
                                                int level, int with_checksum, void* d_slots,

@@ -11,8 +11,8 @@ mib = int(os.environ.get("EB_MIB", "64")); tiles = int(os.environ.get("EB_TILES"
 data = corpus.synth_text(mib << 20, seed=1)
 dev = torch.device("cuda", 0)
 base = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
-d_src = base.repeat(tiles)
-n = d_src.numel(); nb = (n + bs - 1) // bs
+d_src = torch.cat([base.repeat(tiles), torch.zeros(256, dtype=torch.uint8, device=dev)])  # (readable slack: include/zxc_mi355x.h)
+n = d_src.numel() - 256; nb = (n + bs - 1) // bs
 L = zxc_amd.lib()
 stride = L.zxc_mi355x_encode_slot_stride(bs)
 d_slots = torch.empty(nb * stride, dtype=torch.uint8, device=dev)

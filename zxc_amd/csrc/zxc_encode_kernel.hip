@@ -359,6 +359,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         const uint32_t etot = (uint32_t)__builtin_amdgcn_readlane((int)eincl, 63);
         const uint32_t nsel = __popcll(sel);
         if (seq_count + nsel > max_seq || ext_count + etot > ext_cap) { overflow = true; break; }
+#ifndef EXP_ENC_NOSTORE  // (experiment, wrong output: the main loop without its emission stores)
         if (issel) {
             const uint32_t sidx = seq_count + __popcll(below);
             if (GHI) {  // 32-bit word LL(8) | ML-5(8) | offset-1(16), src/lib/zxc_compress.c:1907-1913
@@ -373,6 +374,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             if (ll >= esc) { put_varint(e, ll - esc); e += varint_len(ll - esc); }
             if (mlm >= esc) put_varint(e, mlm - esc);
         }
+#endif
         // only the 8-bit / 16-bit offset decision needs the maximum: one ballot instead of a wave reduction
         if (__ballot(issel && dist > 256u)) max_off = 65535u;
         else if (sel && max_off == 0u) max_off = 1u;
@@ -393,7 +395,9 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         const uint64_t litmask = __ballot(islit);
         // (the byte is already here: low byte of the 16 fetched for this position; only the block's last 16
         // positions, which never start a match, were not fetched)
+#ifndef EXP_ENC_NOSTORE
         if (islit) lit_out[lit_count + __popcll(litmask & lt_mask)] = can ? (uint8_t)v : (uint8_t)e_ld8(in + i);
+#endif
         lit_count += __popcll(litmask);
         seq_count += nsel;
         ext_count += etot;
