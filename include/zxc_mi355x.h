@@ -35,6 +35,8 @@ typedef struct zxc_dev_job {
 ZXC_EXPORT int zxc_mi355x_device_count(void);
 /* Select the device used by the calling thread (hipSetDevice). */
 ZXC_EXPORT int zxc_mi355x_set_device(int device);
+/* The device the calling thread uses (hipGetDevice), or a negative zxc_error_t. */
+ZXC_EXPORT int zxc_mi355x_get_device(void);
 
 /* Device memory helpers so a C caller needs no HIP headers. */
 ZXC_EXPORT void* zxc_mi355x_malloc(size_t bytes);

@@ -92,6 +92,36 @@ def test_stream_compress_round_trips_through_the_reference(product, ref, tmp_pat
 
 
 @pytest.mark.gpu
+def test_stream_compress_with_dictionary(product, ref, tmp_path, monkeypatch):
+    """zxc_stream_compress with opts.dict (reference: the same opts reach zxc_stream_engine_run, src/lib/zxc_driver.c:1038):
+    the archive carries the dictionary id, the unmodified reference decodes it with the dictionary and refuses it without."""
+    monkeypatch.setenv("ZXC_STREAM_BATCH_BYTES", str(2 << 20))
+    rec = b"".join(b'{"id": %d, "name": "user%d", "status": "active", "tags": ["a", "b"]}\n' % (i, i % 97) for i in range(30000))
+    d = rec[:8192]
+    src = tmp_path / "in.bin"
+    src.write_bytes(rec)
+    arc = tmp_path / "d.zxc"
+    plain = tmp_path / "p.zxc"
+    n = product.api.stream_compress(str(src), str(arc), level=3, block_size=4096, checksum=True, dict_=d)
+    assert n == arc.stat().st_size
+    assert product.api.stream_compress(str(src), str(plain), level=3, block_size=4096, checksum=True) > n  # the dictionary pays
+    import ctypes as C
+    import oracle_py
+    comp = arc.read_bytes()
+    assert oracle_py.bind_block_api(ref.lib).zxc_get_dict_id(comp, len(comp)) != 0
+    o = oracle_py.DecompressOpts(checksum_enabled=1)
+    keep = C.create_string_buffer(d, len(d))
+    o.dict, o.dict_size = C.cast(keep, C.c_void_p), len(d)
+    out = C.create_string_buffer(len(rec))
+    assert ref.lib.zxc_decompress(comp, len(comp), out, len(rec), C.byref(o)) == len(rec) and out.raw == rec
+    assert ref.decompress(comp, len(rec), checksum=True)[0] == -15  # ZXC_ERROR_DICT_REQUIRED
+    back = tmp_path / "back.bin"
+    assert product.api.stream_decompress(str(arc), str(back), checksum=True, dict_=d) == len(rec)
+    assert back.read_bytes() == rec
+    assert product.api.stream_decompress(str(arc), str(back), checksum=True) == -15
+
+
+@pytest.mark.gpu
 def test_seekable_open_file(product, manifest, synth_inputs):
     L = product.api._bind_stream(product.lib())
     name = "text_200k_l3_b4k"

@@ -266,18 +266,32 @@ def _bind_stream(L):
     return L
 
 
-def stream_compress(src_path, dst_path, level=3, block_size=65536, seekable=True, checksum=False, library=None):
+def _set_dict(o, dict_, dict_huf):
+    """Point an opts struct at a dictionary (content + optional 128-byte shared table); returns the buffers to keep alive."""
+    if not dict_:
+        return None
+    keep = (C.create_string_buffer(dict_, len(dict_)), C.create_string_buffer(dict_huf, 128) if dict_huf else None)
+    o.dict = C.cast(keep[0], C.c_void_p)
+    o.dict_size = len(dict_)
+    o.dict_huf = C.cast(keep[1], C.c_void_p) if dict_huf else None
+    return keep
+
+
+def stream_compress(src_path, dst_path, level=3, block_size=65536, seekable=True, checksum=False, library=None, dict_=None,
+                    dict_huf=None):
     """zxc_stream_compress(): file in, archive out. Returns bytes written or a negative zxc_error_t."""
     L = _bind_stream(library or lib())
     o = _CompressOpts(level=level, block_size=block_size, seekable=int(seekable), checksum_enabled=int(checksum))
+    _keep = _set_dict(o, dict_, dict_huf)
     with _File(src_path, "rb") as fi, _File(dst_path, "wb") as fo:
         return int(L.zxc_stream_compress(fi, fo, C.byref(o)))
 
 
-def stream_decompress(src_path, dst_path, checksum=False, library=None):
+def stream_decompress(src_path, dst_path, checksum=False, library=None, dict_=None, dict_huf=None):
     """zxc_stream_decompress(): archive in, file out (dst_path None = integrity check only)."""
     L = _bind_stream(library or lib())
     o = _DecompressOpts(checksum_enabled=int(checksum))
+    _keep = _set_dict(o, dict_, dict_huf)
     with _File(src_path, "rb") as fi:
         if dst_path is None:
             return int(L.zxc_stream_decompress(fi, None, C.byref(o)))

@@ -87,6 +87,11 @@ int zxc_mi355x_set_device(int device) {
     return hipSetDevice(device) == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
 }
 
+int zxc_mi355x_get_device(void) {
+    int d = -1;
+    return hipGetDevice(&d) == hipSuccess ? d : ZXC_ERROR_GPU_UNAVAILABLE;
+}
+
 void* zxc_mi355x_malloc(size_t bytes) {
     void* p = NULL;
     if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return NULL;
