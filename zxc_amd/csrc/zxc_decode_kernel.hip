@@ -1098,6 +1098,9 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
     const uint8_t* pdata = data + 12 + desc;
     const uint32_t avail = comp_sz - 12u - desc;
     S.lit = pdata;
+#ifdef ZXC_LEAN_KERNEL  // the variant for blocks whose sections are all raw: no RLE / PivCo callees, no scratch
+    if (enc_lit != 0u || enc_tok != 0u) return ZXC_DEV_E_UNSUPPORTED;
+#else
     if (enc_lit == 2u || enc_lit == 3u) {
         if (lit_comp > avail) return E_CORRUPT;
         if (S.n_lit != 0u) {
@@ -1124,10 +1127,12 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
     } else if (enc_lit != 0u) {
         return E_CORRUPT;
     }
+#endif
     const uint64_t sz_off = (uint64_t)S.n_seq * (enc_off ? 1u : 2u);
     const uint64_t consumed = (uint64_t)lit_comp + tok_comp + sz_off;
     if (consumed > avail || avail - lit_comp < 32u) return E_CORRUPT;
     S.tok = pdata + lit_comp;
+#ifndef ZXC_LEAN_KERNEL
     if (enc_tok == 2u) {  // level 7: the token bytes are a PivCo section too
         if (S.n_seq > block_size / 5u + 16u) return E_CORRUPT;
         uint8_t* scratch = scratch_acquire(pool, lane);
@@ -1141,6 +1146,7 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
     } else if (enc_tok != 0u) {
         return E_CORRUPT;
     }
+#endif
     S.offs = pdata + lit_comp + tok_comp;
     S.off8 = enc_off;
     S.ext = S.offs + sz_off;
@@ -1164,7 +1170,7 @@ __device__ __forceinline__ void decode_one_block(const uint8_t* __restrict__ com
                                                  const uint8_t* __restrict__ dict_huf) {
     // One workgroup (= one wavefront) per block: the hardware dispatcher hands out blocks as
     // wave slots free up, which is all the dynamic scheduling RAW-vs-dense blocks need.
-#ifdef EXP_NO_PIV_LDS  // experiment only: occupancy without the PivCo tables (levels 6-7 break)
+#if defined(EXP_NO_PIV_LDS) || defined(ZXC_LEAN_KERNEL)  // (experiment: occupancy without the PivCo tables; lean variant: never decodes a section)
     __shared__ union { WaveLds w; } lds;
 #else
     __shared__ union { WaveLds w; PivLds p; } lds;  // the PivCo tables reuse the ring's LDS (never live together)
