@@ -625,15 +625,15 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
 // sufficient_len 16/18/16/18/256/256/256, lazy probes 0/0/1/1(+ip+2)/1(+ip+2)/0/0; levels 1-2 emit GHI and use
 // the 4-byte hash, levels >= 3 GLO and the 5-byte hash. Here every position is inserted, so chains are denser
 // than the CPU's and the deep levels walk fewer links for the same reach; LDS per wave (= occupancy) grows with
-// the level: 8 / 12 / 24 / 24 / 64 / 64 / 64 KiB.
+// the level: 8 / 12 / 24 / 24 / 48 / 48 / 48 KiB.
 //   level   head   chain ring   depth   sufficient   lazy   block type
 //     1     2^12      -           1        16          0      GHI
 //     2     2^12     2^11         3        18          0      GHI
 //     3     2^13     2^12         3        16          1      GLO
 //     4     2^13     2^12         6        18          2      GLO
-//     5     2^14     2^14        18       256          2      GLO
-//     6     2^14     2^14        33       256          2      GLO   (optimal parse / PivCo coding: not on the device yet)
-//     7     2^14     2^14        66       256          2      GLO
+//     5     2^13     2^14        18       256          2      GLO
+//     6     2^13     2^14        33       256          2      GLO   (+ PivCo literals; lazy parse, not the reference's optimal parse)
+//     7     2^13     2^14        66       256          2      GLO
 #define ZXC_ENCODE_ENTRY(name, hb, cwb, ghi, waves)                                                                    \
     extern "C" __global__ void __launch_bounds__(64, waves) name(                                                      \
         const uint8_t* __restrict__ src, uint64_t src_size, uint32_t block_size, uint8_t* __restrict__ slots,          \
@@ -650,7 +650,11 @@ ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l2, 12u, 11u, true, 3)   // level 2
 #define ENC_L34_WAVES 2
 #endif
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l34, ENC_L34_HB, ENC_L34_CWB, false, ENC_L34_WAVES) // levels 3-4
-ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l57, 14u, 14u, false, 1) // levels 5-7
+#ifndef ENC_L57_HB  // (A/B: tools/build_enc_variant.sh)
+#define ENC_L57_HB 13u   // (A/B at level 5 on text, head / ring: 2^14 / 2^14 3.70 GB/s ratio 2.301; 2^13 / 2^14 4.76, 2.287;
+#define ENC_L57_CWB 14u  //  2^14 / 2^13 4.99, 2.275; 2^13 / 2^13 6.30, 2.249: the head table is the cheaper one to halve)
+#endif
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l57, ENC_L57_HB, ENC_L57_CWB, false, 1) // levels 5-7
 
 // [dict | block b] images for the dictionary path: work + b * (block_size + dict_size)
 extern "C" __global__ void __launch_bounds__(64)
