@@ -67,6 +67,12 @@ typedef v4u __attribute__((aligned(1))) v4u_unaligned;
 #ifndef LIT_LOOP2
 #define LIT_LOOP2 1      // literal groups beyond the third: two per step, requested unconditionally (0: one conditional load per step)
 #endif
+#ifndef LIT_PRELOAD
+#define LIT_PRELOAD 3    // literal groups of a run requested before the dependency analysis (2: the third joins the loop; register diet A/B)
+#endif
+#ifndef FAR_PRELOAD
+#define FAR_PRELOAD 2    // far-source groups of a match requested before the literal puts (1: the second is fetched in its step)
+#endif
 #ifndef FAR_EARLY
 #define FAR_EARLY 0      // far-source groups: 0 requested after the literal wait; 1 by every lane, unconditionally, before it (A/B: -6.5 %);
                          // 2 by the lanes that need them, before the dependency analysis (A/B: -4.5 %)
@@ -642,11 +648,16 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             const uint32_t le = la + ll;              // end of the run on its grid (bytes from the grid origin)
             const bool lshort = mine && ll != 0u && ll <= LIT_MED;
             const uint8_t* lsrc = S.lit + (int32_t)(lst - la);
-            v4u lv0 = {0, 0, 0, 0}, lv1 = {0, 0, 0, 0}, lv2 = {0, 0, 0, 0};
+            v4u lv0 = {0, 0, 0, 0}, lv1 = {0, 0, 0, 0};
+#if LIT_PRELOAD >= 3
+            v4u lv2 = {0, 0, 0, 0};
+#endif
             if (lshort) {
                 lv0 = ld128(lsrc);
                 if (le > 16u) lv1 = ld128(lsrc + 16u);
+#if LIT_PRELOAD >= 3
                 if (le > 32u) lv2 = ld128(lsrc + 32u);
+#endif
             }
 
             // ---- matches. Sequence i may only copy once every earlier match of this batch
@@ -741,7 +752,9 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
             far_waited = true;
             if (pf) {
                 fr0 = __builtin_nontemporal_load((const v4u_unaligned*)(O.dst + sg));
+#if FAR_PRELOAD >= 2
                 if (me > 16u) fr1 = __builtin_nontemporal_load((const v4u_unaligned*)(O.dst + sg + 16u));
+#endif
             }
 #endif
             PH(2);
@@ -758,13 +771,15 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                     const uint32_t t = (lshort && le > 16u) ? (le - 16u < 16u ? le - 16u : 16u) : 0u;
                     ring_or_group(L, lg + 16u, group_keep_first(L, lv1, t));
                 }
+#if LIT_PRELOAD >= 3
                 if (__ballot(lshort && le > 32u)) {
                     const uint32_t t = (lshort && le > 32u) ? (le - 32u < 16u ? le - 32u : 16u) : 0u;
                     ring_or_group(L, lg + 32u, group_keep_first(L, lv2, t));
                 }
+#endif
 #if LIT_LOOP2
 #pragma unroll 1
-                for (uint32_t go = 48u; go < LIT_MED + 4u; go += 32u) {  // two groups per step, both requested by every lane
+                for (uint32_t go = LIT_PRELOAD >= 3 ? 48u : 32u; go < LIT_MED + 4u; go += 32u) {  // two groups per step, both requested by every lane
                     const bool actA = lshort && le > go, actB = lshort && le > go + 16u;
                     if (__ballot(actA) == 0ull) break;
                     // (a load under a condition is waited for on the spot: idle lanes re-read the start of the literal stream)
@@ -810,7 +825,7 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
                         const bool act = sa && me > go;
                         if (__ballot(act) == 0ull) break;
                         const uint32_t q = sg + go;                       // source of this group
-                        const bool usepf = act && pf && go < 32u;         // requested before the literal puts
+                        const bool usepf = act && pf && go < 16u * FAR_PRELOAD;  // requested before the literal puts
                         const bool isfar = act && !usepf && farsrc && q < ring_lo;  // (farsrc lanes have qsrc >= 4: q does not wrap)
                         v4u d = {0, 0, 0, 0};
                         if (usepf) d = go == 0u ? fr0 : fr1;
