@@ -240,27 +240,27 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             const bool act = d != 0u && tried < depth && len < sufficient;
             if (__ballot(act) == 0ull) break;
             uint32_t da = act ? d : 0u, db = 0, dc = 0, dn = 0;
-            if (CWB) {
-                // a link is still in the ring while no newer position has taken its slot
-                auto next = [&](uint32_t dk, bool want) -> uint32_t {
-                    if (!want || dk == 0u || dk + 64u - (uint32_t)lane > CW) return 0u;
-                    const uint32_t dl = chain[(i - dk) & CWM];
-                    const uint32_t r = dk + dl;
-                    return (dl != 0u && r <= 0xFFFFu && r <= i) ? r : 0u;
-                };
-                db = next(da, tried + 1u < depth);
-                dc = next(db, tried + 2u < depth);
-                dn = next(dc, tried + 3u < depth);
-            }
+            // a link is still in the ring while no newer position has taken its slot
+            auto next = [&](uint32_t dk, bool want) -> uint32_t {
+                if (!CWB || !want || dk == 0u || dk + 64u - (uint32_t)lane > CW) return 0u;
+                const uint32_t dl = chain[(i - dk) & CWM];
+                const uint32_t r = dk + dl;
+                return (dl != 0u && r <= 0xFFFFu && r <= i) ? r : 0u;
+            };
             // 32 bytes of every candidate (and my own second 16) are requested together: most matches end inside
             // them, so a round costs ONE memory round trip; only longer ones enter the extension loop below
             // (requested by every lane — a lane without that candidate re-reads its own position — so that the seven
-            // loads are issued back to back and waited for once: a load under a condition is waited for on the spot)
+            // loads are issued back to back and waited for once: a load under a condition is waited for on the spot).
+            // Each candidate's bytes are requested as soon as its distance is known: the two further chain links are
+            // dependent LDS reads, and their latency then runs under the first candidate's memory round trip.
             const uint8_t* pme = can ? in + i : in;
             const v4u ca = e_ld128(pme - da), ca2 = e_ld128(pme - da + 16u);
-            const v4u cb = e_ld128(pme - db), cb2 = e_ld128(pme - db + 16u);
-            const v4u cc = e_ld128(pme - dc), cc2 = e_ld128(pme - dc + 16u);
             const v4u own2 = e_ld128(pme + 16u);  // (may reach up to 16 bytes past the block: lengths are clamped to it below)
+            db = next(da, tried + 1u < depth);
+            const v4u cb = e_ld128(pme - db), cb2 = e_ld128(pme - db + 16u);
+            dc = next(db, tried + 2u < depth);
+            const v4u cc = e_ld128(pme - dc), cc2 = e_ld128(pme - dc + 16u);
+            dn = next(dc, tried + 3u < depth);
             const uint64_t o2lo = (uint64_t)own2.x | ((uint64_t)own2.y << 32), o2hi = (uint64_t)own2.z | ((uint64_t)own2.w << 32);
             uint32_t ma = da ? prefix16(v, vh, ca) : 0u, mb = db ? prefix16(v, vh, cb) : 0u, mc = dc ? prefix16(v, vh, cc) : 0u;
             if (ma == 16u) ma += prefix16(o2lo, o2hi, ca2);
