@@ -13,9 +13,10 @@
 //      position to the previous one with the same hash. EVERY position is inserted (the CPU inserts only the
 //      positions its parse visits), so a chain here is denser than the reference's and needs fewer steps;
 //   2. each lane walks its own chain for up to `depth` candidates, three per round: the links are LDS reads,
-//      the three candidates' 16 bytes are requested together (one memory round trip per round), compared
-//      with 64-bit XOR + ctz, the longest kept; a candidate that matches all 16 bytes is extended 8 bytes at
-//      a time; the walk stops at `sufficient` bytes like the reference's;
+//      32 bytes of every candidate are requested as soon as its distance is known (one memory round trip per
+//      round), compared with 64-bit XOR + ctz, the longest kept; candidates still equal after 32 bytes are
+//      extended together, 16 bytes per step (A/B: 32 bytes per step with every load unconditional is 3 % slower
+//      at level 3, the same at levels 5-7); the walk stops at `sufficient` bytes like the reference's;
 //   3. the chunk's positions are published: chain link = distance to the old head, head = own position; lanes
 //      that share a bucket resolve it deterministically (highest position wins, re-checked until stable);
 //   4. the scalar unit walks the chunk's match lengths with v_readlane: greedy parse with the level's lazy
@@ -27,9 +28,9 @@
 // Finally the literal section is RLE-coded when that is smaller by the reference's margin
 // (zxc_compress.c:1270-1534, :1671-1722), the sections are slid together into the reference's layout, or
 // the block is stored RAW when that is not smaller. Levels differ in effort (table sizes, chain depth,
-// sufficient length, lazy probes: table at the bottom). Not done here: the level-6/7 optimal parse and
-// PivCo literal / token coding (levels 6-7 emit GLO with RAW / RLE literals). Output is a valid v8 block,
-// round-trip-checked by tests/ against the unmodified reference decoder; archive bytes are deterministic.
+// sufficient length, lazy probes: table at the bottom); levels 6-7 code the literal section (7: and the token
+// section) with PivCo (zxc_pivco_encode.inc). Not done here: the level-6/7 optimal parse. Output is a valid v8
+// block, round-trip-checked by tests/ against the unmodified reference decoder; archive bytes are deterministic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -38,9 +39,8 @@
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
-// Hash table size per level class (entries): the table is the LDS footprint, i.e. the occupancy:
-// 2^12 -> 8 KiB (20 waves/CU), 2^13 -> 16 KiB (10), 2^14 -> 32 KiB (5). Measured on the text corpus:
-// 66 / 42 / 24 GB/s at ratio 1.82 / 1.92 / 1.99 (reference level 3: 1.86).
+// The head table + chain ring are the LDS footprint, i.e. the occupancy (sizes per level: table at the bottom;
+// measured trade-offs: profiles/r2o_encode_table_sizes_ab.log).
 #define ENC_MARGIN 8u   // the last 8 bytes of a block never start a match (reference ZXC_LZ_SEARCH_MARGIN)
 // Table entries are the low 16 bits of a position: offsets are < 65536 anyway, so the candidate is
 // i - ((i - entry) & 0xFFFF); a stale or never-written entry just names some older position, and
