@@ -134,7 +134,7 @@ __device__ __forceinline__ uint32_t prefix16(uint64_t a_lo, uint64_t a_hi, const
 //   GHI: 4-byte words), offsets (GLO), extras
 // HB = log2(head entries), CWB = log2(chain ring entries) or 0 for "head only". depth / sufficient / lazy: the
 // reference's search_depth / sufficient_len / lazy probes (src/lib/zxc_internal.h:965-979), see the table below.
-template <uint32_t HB, uint32_t CWB, bool GHI>
+template <uint32_t HB, uint32_t CWB, bool GHI, uint32_t NC>
 __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src, uint64_t src_size, uint32_t block_size,
                                                  uint8_t* __restrict__ slots, uint32_t slot_stride,
                                                  uint32_t* __restrict__ sizes, uint32_t n_blocks, uint32_t with_checksum,
@@ -234,12 +234,11 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             d0 = (i - (uint32_t)ht[h]) & 0xFFFFu;  // entries hold 16 bits of a position; every candidate is verified
             if (d0 > i) d0 = 0;                    // (0: none)
         }
-        // ---- 2. chain walk, three candidates per round (zxc_lz77_find_best_match :262-440)
+        // ---- 2. chain walk, NC candidates per round (zxc_lz77_find_best_match :262-440)
         uint32_t len = 0, dist = 0, tried = 0, d = d0;
         for (;;) {
             const bool act = d != 0u && tried < depth && len < sufficient;
             if (__ballot(act) == 0ull) break;
-            uint32_t da = act ? d : 0u, db = 0, dc = 0, dn = 0;
             // a link is still in the ring while no newer position has taken its slot
             auto next = [&](uint32_t dk, bool want) -> uint32_t {
                 if (!CWB || !want || dk == 0u || dk + 64u - (uint32_t)lane > CW) return 0u;
@@ -249,54 +248,67 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             };
             // 32 bytes of every candidate (and my own second 16) are requested together: most matches end inside
             // them, so a round costs ONE memory round trip; only longer ones enter the extension loop below
-            // (requested by every lane — a lane without that candidate re-reads its own position — so that the seven
+            // (requested by every lane — a lane without that candidate re-reads its own position — so that the
             // loads are issued back to back and waited for once: a load under a condition is waited for on the spot).
-            // Each candidate's bytes are requested as soon as its distance is known: the two further chain links are
+            // Each candidate's bytes are requested as soon as its distance is known: the further chain links are
             // dependent LDS reads, and their latency then runs under the first candidate's memory round trip.
             const uint8_t* pme = can ? in + i : in;
-            const v4u ca = e_ld128(pme - da), ca2 = e_ld128(pme - da + 16u);
+            uint32_t dk[NC + 1];
+            v4u c1[NC], c2[NC];
+            dk[0] = act ? d : 0u;
             const v4u own2 = e_ld128(pme + 16u);  // (may reach up to 16 bytes past the block: lengths are clamped to it below)
-            db = next(da, tried + 1u < depth);
-            const v4u cb = e_ld128(pme - db), cb2 = e_ld128(pme - db + 16u);
-            dc = next(db, tried + 2u < depth);
-            const v4u cc = e_ld128(pme - dc), cc2 = e_ld128(pme - dc + 16u);
-            dn = next(dc, tried + 3u < depth);
+#pragma unroll
+            for (uint32_t k = 0; k < NC; k++) {
+                c1[k] = e_ld128(pme - dk[k]);
+                c2[k] = e_ld128(pme - dk[k] + 16u);
+                dk[k + 1] = next(dk[k], tried + k + 1u < depth);
+            }
             const uint64_t o2lo = (uint64_t)own2.x | ((uint64_t)own2.y << 32), o2hi = (uint64_t)own2.z | ((uint64_t)own2.w << 32);
-            uint32_t ma = da ? prefix16(v, vh, ca) : 0u, mb = db ? prefix16(v, vh, cb) : 0u, mc = dc ? prefix16(v, vh, cc) : 0u;
-            if (ma == 16u) ma += prefix16(o2lo, o2hi, ca2);
-            if (mb == 16u) mb += prefix16(o2lo, o2hi, cb2);
-            if (mc == 16u) mc += prefix16(o2lo, o2hi, cc2);
+            uint32_t mk[NC];
+            bool lk[NC];
+            bool anylive = false;
+#pragma unroll
+            for (uint32_t k = 0; k < NC; k++) {
+                mk[k] = dk[k] ? prefix16(v, vh, c1[k]) : 0u;
+                if (mk[k] == 16u) mk[k] += prefix16(o2lo, o2hi, c2[k]);
+                lk[k] = mk[k] == 32u;
+                anylive |= lk[k];
+            }
             // candidates still equal after 32 bytes are extended TOGETHER, 16 bytes per step: one request for my own
             // bytes and one per live candidate, all in flight at once, so a step costs one memory round trip however
             // many candidates are still running (the reference extends them one after the other, 8 bytes at a time)
             {
-                bool la = ma == 32u, lb = mb == 32u, lc = mc == 32u;
                 uint32_t L = 32u;
-                while (la | lb | lc) {
+                while (anylive) {
                     if (i + L + 16u > n) {  // block tail: finish bytewise
-                        if (la) { ma = L; while (i + ma < n && in[i + ma] == in[i - da + ma]) ma++; la = false; }
-                        if (lb) { mb = L; while (i + mb < n && in[i + mb] == in[i - db + mb]) mb++; lb = false; }
-                        if (lc) { mc = L; while (i + mc < n && in[i + mc] == in[i - dc + mc]) mc++; lc = false; }
+#pragma unroll
+                        for (uint32_t k = 0; k < NC; k++)
+                            if (lk[k]) { mk[k] = L; while (i + mk[k] < n && in[i + mk[k]] == in[i - dk[k] + mk[k]]) mk[k]++; lk[k] = false; }
                         break;
                     }
                     const v4u own = e_ld128(in + i + L);
-                    v4u xa = own, xb = own, xc = own;
-                    if (la) xa = e_ld128(in + i - da + L);
-                    if (lb) xb = e_ld128(in + i - db + L);
-                    if (lc) xc = e_ld128(in + i - dc + L);
+                    v4u xk[NC];
+#pragma unroll
+                    for (uint32_t k = 0; k < NC; k++) {
+                        xk[k] = own;
+                        if (lk[k]) xk[k] = e_ld128(in + i - dk[k] + L);
+                    }
                     const uint64_t olo = (uint64_t)own.x | ((uint64_t)own.y << 32), ohi = (uint64_t)own.z | ((uint64_t)own.w << 32);
-                    if (la) { const uint32_t m = prefix16(olo, ohi, xa); if (m < 16u) { ma = L + m; la = false; } }
-                    if (lb) { const uint32_t m = prefix16(olo, ohi, xb); if (m < 16u) { mb = L + m; lb = false; } }
-                    if (lc) { const uint32_t m = prefix16(olo, ohi, xc); if (m < 16u) { mc = L + m; lc = false; } }
+                    anylive = false;
+#pragma unroll
+                    for (uint32_t k = 0; k < NC; k++) {
+                        if (lk[k]) { const uint32_t m = prefix16(olo, ohi, xk[k]); if (m < 16u) { mk[k] = L + m; lk[k] = false; } }
+                        anylive |= lk[k];
+                    }
                     L += 16u;
                 }
                 // (the tail path above clamps at n; a 16 / 32-byte prefix that straddles the block end is clamped below)
             }
-            if (ma > len) { len = ma; dist = da; }   // (first = nearest wins ties: smaller offsets, cheaper tokens)
-            if (mb > len) { len = mb; dist = db; }
-            if (mc > len) { len = mc; dist = dc; }
-            tried += 3u;
-            d = dn;
+#pragma unroll
+            for (uint32_t k = 0; k < NC; k++)
+                if (mk[k] > len) { len = mk[k]; dist = dk[k]; }   // (first = nearest wins ties: smaller offsets, cheaper tokens)
+            tried += NC;
+            d = dk[NC];
         }
         if (len > n - i) len = n - i;
         if (len < 5u) { len = 0; dist = 0; }
@@ -634,27 +646,30 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
 //     5     2^13     2^14        18       256          2      GLO
 //     6     2^13     2^14        33       256          2      GLO   (+ PivCo literals; lazy parse, not the reference's optimal parse)
 //     7     2^13     2^14        66       256          2      GLO
-#define ZXC_ENCODE_ENTRY(name, hb, cwb, ghi, waves)                                                                    \
+#define ZXC_ENCODE_ENTRY(name, hb, cwb, ghi, waves, nc)                                                                    \
     extern "C" __global__ void __launch_bounds__(64, waves) name(                                                      \
         const uint8_t* __restrict__ src, uint64_t src_size, uint32_t block_size, uint8_t* __restrict__ slots,          \
         uint32_t slot_stride, uint32_t* __restrict__ sizes, uint32_t n_blocks, uint32_t with_checksum, uint32_t depth, \
         uint32_t sufficient, uint32_t lazy, uint32_t dict_size, uint8_t* __restrict__ huf_scratch, uint32_t huf) {     \
-        encode_one_block<hb, cwb, ghi>(src, src_size, block_size, slots, slot_stride, sizes, n_blocks, with_checksum,  \
+        encode_one_block<hb, cwb, ghi, nc>(src, src_size, block_size, slots, slot_stride, sizes, n_blocks, with_checksum,  \
                                        depth, sufficient, lazy, dict_size, huf_scratch, huf);                          \
     }
-ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l1, 12u, 0u, true, 5)    // level 1
-ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l2, 12u, 11u, true, 3)   // level 2
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l1, 12u, 0u, true, 5, 3u)    // level 1 (A/B: one candidate per round instead of three: -3 %)
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l2, 12u, 11u, true, 3, 3u)   // level 2
 #ifndef ENC_L34_HB  // (A/B: tools/build_enc_variant.sh)
 #define ENC_L34_HB 13u
 #define ENC_L34_CWB 12u
 #define ENC_L34_WAVES 2
 #endif
-ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l34, ENC_L34_HB, ENC_L34_CWB, false, ENC_L34_WAVES) // levels 3-4
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l34, ENC_L34_HB, ENC_L34_CWB, false, ENC_L34_WAVES, 3u) // levels 3-4
 #ifndef ENC_L57_HB  // (A/B: tools/build_enc_variant.sh)
 #define ENC_L57_HB 13u   // (A/B at level 5 on text, head / ring: 2^14 / 2^14 3.70 GB/s ratio 2.301; 2^13 / 2^14 4.76, 2.287;
 #define ENC_L57_CWB 14u  //  2^14 / 2^13 4.99, 2.275; 2^13 / 2^13 6.30, 2.249: the head table is the cheaper one to halve)
 #endif
-ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l57, ENC_L57_HB, ENC_L57_CWB, false, 1) // levels 5-7
+#ifndef ENC_L57_NC
+#define ENC_L57_NC 6u   // candidates per round of the deep levels (18 / 33 / 66 per position: half the round trips of 3)
+#endif
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l57, ENC_L57_HB, ENC_L57_CWB, false, 1, ENC_L57_NC) // levels 5-7
 
 // [dict | block b] images for the dictionary path: work + b * (block_size + dict_size)
 extern "C" __global__ void __launch_bounds__(64)
