@@ -50,7 +50,7 @@ typedef v4u __attribute__((aligned(1))) v4u_unaligned;
 #define REDIRECT_PASSES 2   // chained containment levels resolved before round 0 (A/B: 0: -6 %, 1: -2 %, 2: best, 3: -1 %)
 #endif
 #ifndef SPARSE_MAX
-#define SPARSE_MAX 8   // at most this many unfinished sequences after a round: finish them one by one (A/B: 2: -0.3 %, 4: 0, 8: +1 %)
+#define SPARSE_MAX 8   // at most this many unfinished sequences after a round: finish them one by one (A/B: 2: -0.3 %, 4: 0, 8: +1 %, 12 / 16: 0)
 #endif
 #ifndef TILE_MAX
 // A batch never spans more output than this: the ring must hold the batch, the not yet flushed tail of the
