@@ -10,6 +10,9 @@
 namespace emu { void run_wave(const std::function<void()>& body, unsigned block, unsigned grid, int n_lanes); }
 extern char __start_emu_lds[], __stop_emu_lds[];
 
+static uint32_t emu_last_deferred = 0;
+extern "C" __attribute__((visibility("default"))) uint32_t emu_last_deferred_count(void) { return emu_last_deferred; }
+
 extern "C" __attribute__((visibility("default")))
 int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_t* jobs, uint32_t n_jobs, uint8_t* out,
                       size_t out_bytes, int32_t* status, uint32_t block_size, int verify_trailer, const uint8_t* dict,
@@ -24,19 +27,47 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
     std::vector<uint8_t> dct;
     const uint8_t* dptr = nullptr;
     if (dict && dict_size) { dct.assign(dict_size + 8192, 0xBB); memcpy(dct.data() + 4096, dict, dict_size); dptr = dct.data() + 4096; }
-    for (uint32_t b = 0; b < n_jobs; b++) {
-        memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));  // LDS is not zero at launch
-        if (dptr || dict_huf)
+    if (dptr || dict_huf) {
+        for (uint32_t b = 0; b < n_jobs; b++) {
+            memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));  // LDS is not zero at launch
             emu::run_wave([&] {
                 zxc_decode_blocks_dict_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size,
                                               verify_trailer ? 4u : 0u, scratch.data(), stride, 0u, busy.data(), n_slots,
                                               nullptr, 0u, dptr, dict_size, dict_huf);
             }, b, n_jobs, 64);
-        else
+        }
+    } else if (verify_trailer) {
+        for (uint32_t b = 0; b < n_jobs; b++) {
+            memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));
             emu::run_wave([&] {
-                zxc_decode_blocks_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size,
-                                         verify_trailer ? 4u : 0u, scratch.data(), stride, 0u, busy.data(), n_slots, nullptr, 0u);
+                zxc_decode_blocks_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, 4u, scratch.data(),
+                                         stride, 0u, busy.data(), n_slots, nullptr, 0u, nullptr);
             }, b, n_jobs, 64);
+        }
+    } else {
+        // the two-pass launch of zxc_hip_shim.hip: the lean kernel over every block (in a launch order that is not the
+        // identity), then the full kernel, a fixed grid walking the list of blocks the lean kernel handed over
+        std::vector<uint32_t> order(n_jobs), list(n_jobs + 1u, 0u);
+        for (uint32_t b = 0; b < n_jobs; b++) {
+            order[b] = n_jobs - 1u - b;
+            // (what zxc_order_scatter_kernel appends, by the same predicate)
+            if (block_needs_full_kernel(c.data() + 4096 + jobs[order[b]].comp_off, jobs[order[b]].comp_size)) list[1u + list[0]++] = b;
+        }
+        for (uint32_t b = 0; b < n_jobs; b++) {
+            memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));
+            emu::run_wave([&] {
+                zxc_decode_blocks_lean_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, order.data(), 0u);
+            }, b, n_jobs, 64);
+        }
+        emu_last_deferred = list[0];
+        const uint32_t grid = n_jobs < 3u ? n_jobs : 3u;
+        for (uint32_t b = 0; b < grid; b++) {
+            memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));
+            emu::run_wave([&] {
+                zxc_decode_blocks_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, 0u, scratch.data(),
+                                         stride, 0u, busy.data(), n_slots, order.data(), 0u, list.data());
+            }, b, grid, 64);
+        }
     }
     memcpy(out, o.data() + 4096, out_bytes);
     return 0;

@@ -103,9 +103,11 @@ typedef v4u __attribute__((aligned(1))) v4u_unaligned;
 #define PHC(i) do { } while (0)
 #endif
 
-struct __attribute__((aligned(16))) WaveLds {
+struct __attribute__((aligned(16))) RingLds {
     uint32_t ring[RING_WORDS];          // last RING_BYTES of output, position p at byte p & RING_MASK; bytes not yet written are zero
     uint32_t tmask[17 * 4];             // tmask[4 t + j]: byte mask of dword j of a 16-byte group that keeps the group's first t bytes
+};
+struct __attribute__((aligned(16))) WaveLds : RingLds {
     uint32_t vval[128];                 // values of the batch's varints, in stream order
     uint32_t vpos[130];                 // their byte positions in the extras stream (+ end cursor)
 };
@@ -157,13 +159,13 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // ------------------------------------------------------------------ ring access
-__device__ __forceinline__ uint8_t* ring8(WaveLds& L) { return (uint8_t*)L.ring; }
-__device__ __forceinline__ uint32_t ring_rd8(WaveLds& L, uint32_t pos) { return LDS_LD8(ring8(L) + (pos & RING_MASK)); }
-__device__ __forceinline__ void ring_wr8(WaveLds& L, uint32_t pos, uint32_t v) { LDS_ST8(ring8(L) + (pos & RING_MASK), v); }
-__device__ __forceinline__ uint32_t ring_rd32(WaveLds& L, uint32_t pos4) { return LDS_LD32(ring8(L) + (pos4 & RING_MASK)); }
-__device__ __forceinline__ void ring_or32(WaveLds& L, uint32_t pos4, uint32_t v) { LDS_OR32(ring8(L) + (pos4 & RING_MASK), v); }
+__device__ __forceinline__ uint8_t* ring8(RingLds& L) { return (uint8_t*)L.ring; }
+__device__ __forceinline__ uint32_t ring_rd8(RingLds& L, uint32_t pos) { return LDS_LD8(ring8(L) + (pos & RING_MASK)); }
+__device__ __forceinline__ void ring_wr8(RingLds& L, uint32_t pos, uint32_t v) { LDS_ST8(ring8(L) + (pos & RING_MASK), v); }
+__device__ __forceinline__ uint32_t ring_rd32(RingLds& L, uint32_t pos4) { return LDS_LD32(ring8(L) + (pos4 & RING_MASK)); }
+__device__ __forceinline__ void ring_or32(RingLds& L, uint32_t pos4, uint32_t v) { LDS_OR32(ring8(L) + (pos4 & RING_MASK), v); }
 // 16 bytes starting at any position: aligned dword reads + v_alignbyte
-__device__ __forceinline__ v4u ring_rd128(WaveLds& L, uint32_t pos) {
+__device__ __forceinline__ v4u ring_rd128(RingLds& L, uint32_t pos) {
     const uint32_t b = pos & ~3u;
     const uint32_t sh = pos & 3u;
     const uint32_t w0 = ring_rd32(L, b), w1 = ring_rd32(L, b + 4u), w2 = ring_rd32(L, b + 8u), w3 = ring_rd32(L, b + 12u),
@@ -175,18 +177,18 @@ __device__ __forceinline__ v4u ring_rd128(WaveLds& L, uint32_t pos) {
     r.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
     return r;
 }
-__device__ __forceinline__ v4u ring_rd128_aligned(WaveLds& L, uint32_t pos16) { return LDS_LD128(ring8(L) + (pos16 & RING_MASK)); }
-__device__ __forceinline__ void ring_wr128_aligned(WaveLds& L, uint32_t pos16, v4u v) { LDS_ST128(ring8(L) + (pos16 & RING_MASK), v); }
+__device__ __forceinline__ v4u ring_rd128_aligned(RingLds& L, uint32_t pos16) { return LDS_LD128(ring8(L) + (pos16 & RING_MASK)); }
+__device__ __forceinline__ void ring_wr128_aligned(RingLds& L, uint32_t pos16, v4u v) { LDS_ST128(ring8(L) + (pos16 & RING_MASK), v); }
 
 // A group = 4 dwords of the destination's dword grid (16 bytes at a 4-aligned position).
 // Keeps the first t (0..16) bytes of a group.
-__device__ __forceinline__ v4u group_keep_first(WaveLds& L, const v4u d, uint32_t t) {
+__device__ __forceinline__ v4u group_keep_first(RingLds& L, const v4u d, uint32_t t) {
     const v4u m = LDS_LD128((const uint8_t*)L.tmask + 16u * t);
     return d & m;
 }
 // Byte mask that clears the first a (0..3) bytes of a dword: bytes [3-a, 7-a) of 00 00 00 FF FF FF FF FF.
 __device__ __forceinline__ uint32_t head_mask(uint32_t a) { return __builtin_amdgcn_alignbyte(0xFFFFFFFFu, 0xFF000000u, 3u - a); }
-__device__ __forceinline__ void ring_or_group(WaveLds& L, uint32_t gpos4, const v4u d) {
+__device__ __forceinline__ void ring_or_group(RingLds& L, uint32_t gpos4, const v4u d) {
     ring_or32(L, gpos4, d.x);
     ring_or32(L, gpos4 + 4u, d.y);
     ring_or32(L, gpos4 + 8u, d.z);
@@ -220,13 +222,13 @@ __device__ __forceinline__ uint32_t far_rd8(const Out& O, uint32_t q) {
 // prefix that logically precedes the block (reference: d_floor = dst - dict_size,
 // src/lib/zxc_decompress.c:1028).
 template <bool DICT>
-__device__ __forceinline__ uint32_t src_rd8(WaveLds& L, const Out& O, uint32_t s, uint32_t ring_lo) {
+__device__ __forceinline__ uint32_t src_rd8(RingLds& L, const Out& O, uint32_t s, uint32_t ring_lo) {
     if (DICT && (int32_t)s < 0) return ld8(O.dict + (int32_t)(O.dict_size + s));
     return s >= ring_lo ? ring_rd8(L, s) : far_rd8(O, s);
 }
 
 // Stream finished output from the ring to HBM: chunks [O.flushed, upto & ~15).
-__device__ __forceinline__ void flush_to(WaveLds& L, Out& O, uint32_t upto, int lane) {
+__device__ __forceinline__ void flush_to(RingLds& L, Out& O, uint32_t upto, int lane) {
     const uint32_t end = upto & ~15u;
     for (uint32_t c = O.flushed + 16u * (uint32_t)lane; c < end; c += 1024u) {
         const v4u v = ring_rd128_aligned(L, c);
@@ -242,7 +244,7 @@ __device__ __forceinline__ void flush_to(WaveLds& L, Out& O, uint32_t upto, int 
 
 // Zero the ring for output positions [from16, to16) (both multiples of 16, at most RING_BYTES apart):
 // the part of the window the coming batch fills with ds_or puts.
-__device__ __forceinline__ void ring_zero(WaveLds& L, uint32_t from16, uint32_t to16, int lane) {
+__device__ __forceinline__ void ring_zero(RingLds& L, uint32_t from16, uint32_t to16, int lane) {
     const v4u z = {0, 0, 0, 0};
     for (uint32_t c = from16 + 16u * (uint32_t)lane; c < to16; c += 1024u) ring_wr128_aligned(L, c, z);
 }
@@ -252,7 +254,7 @@ __device__ __forceinline__ void ring_zero(WaveLds& L, uint32_t from16, uint32_t 
 // destination: n <= dpos - spos) or, when lit != nullptr, the literal stream.
 // Plain (not OR) stores: every destination byte is written exactly once, whatever was there.
 template <bool DICT>
-__device__ void coop_copy(WaveLds& L, const Out& O, uint32_t dpos, uint32_t spos, const uint8_t* lit, uint32_t n,
+__device__ void coop_copy(RingLds& L, const Out& O, uint32_t dpos, uint32_t spos, const uint8_t* lit, uint32_t n,
                           uint32_t ring_lo, int lane) {
     const uint32_t h0 = (16u - (dpos & 15u)) & 15u;
     const uint32_t h = h0 < n ? h0 : n;  // bytes up to the first 16-byte boundary
@@ -290,7 +292,7 @@ __device__ void coop_copy(WaveLds& L, const Out& O, uint32_t dpos, uint32_t spos
 // region has doubled, so double dist (it stays a multiple of off). With flush_each the
 // ring is drained between steps (giant sequences, longer than the ring).
 template <bool DICT>
-__device__ void coop_match(WaveLds& L, Out& O, uint32_t M, uint32_t ml, uint32_t off, uint32_t ring_lo_fixed,
+__device__ void coop_match(RingLds& L, Out& O, uint32_t M, uint32_t ml, uint32_t off, uint32_t ring_lo_fixed,
                            bool flush_each, int lane) {
     uint32_t done = 0, dist = off;
     while (done < ml) {
@@ -326,7 +328,8 @@ __device__ __forceinline__ uint32_t compose_map(uint32_t hi, uint32_t lo) {  // 
     return r;
 }
 
-__device__ __forceinline__ uint32_t parse_varints(const uint8_t* ext, uint32_t ext_size, uint32_t cur, uint32_t nv, WaveLds& L,
+template <typename LDS>  // WaveLds (up to 128 varints per batch) or LeanLds (up to 62)
+__device__ __forceinline__ uint32_t parse_varints(const uint8_t* ext, uint32_t ext_size, uint32_t cur, uint32_t nv, LDS& L,
                                   int lane) {
     const uint32_t base = cur + 8u * (uint32_t)lane;
     uint64_t lo8;
@@ -1182,7 +1185,7 @@ __device__ __forceinline__ void decode_one_block(const uint8_t* __restrict__ com
                                                  uint32_t scratch_stride, uint32_t dbg, uint32_t* __restrict__ slot_busy,
                                                  uint32_t n_slots, const uint32_t* __restrict__ order, uint32_t cap_override,
                                                  const uint8_t* __restrict__ dict, uint32_t dict_size,
-                                                 const uint8_t* __restrict__ dict_huf) {
+                                                 const uint8_t* __restrict__ dict_huf, uint32_t slot) {
     // One workgroup (= one wavefront) per block: the hardware dispatcher hands out blocks as
     // wave slots free up, which is all the dynamic scheduling RAW-vs-dense blocks need.
 #if defined(EXP_NO_PIV_LDS) || defined(ZXC_LEAN_KERNEL)  // (experiment: occupancy without the PivCo tables; lean variant: never decodes a section)
@@ -1192,12 +1195,12 @@ __device__ __forceinline__ void decode_one_block(const uint8_t* __restrict__ com
 #endif
     WaveLds& L = lds.w;
     const int lane = threadIdx.x;
-    if (blockIdx.x >= n_jobs) return;
+    if (slot >= n_jobs) return;
 #ifdef EXP_PIV_PROF
     if (lane < 16) g_piv_prof[lane] = lane == 15 ? (uint32_t)__builtin_readcyclecounter() : 0u;
 #endif
     // heaviest blocks first when the launch is long enough for the tail to matter (see zxc_order_* below)
-    const uint32_t b = order ? uni(order[blockIdx.x]) : blockIdx.x;
+    const uint32_t b = order ? uni(order[slot]) : slot;
 #ifdef EXP_TIMES  // experiment only: status = start (hi 16) and duration (lo 16) in units of 32 ticks of the 100 MHz clock
     const uint64_t t_start = wall_clock64();
 #endif
@@ -1261,16 +1264,23 @@ __device__ __forceinline__ void decode_one_block(const uint8_t* __restrict__ com
     if (lane == 0) status[b] = rc;
 }
 
-// Two entry points: archives without a dictionary (the common case and the benchmarked path) run
-// the variant with every dictionary branch compiled out.
+// Entry points. Archives without a dictionary (the common case and the benchmarked path) run the variant with every
+// dictionary branch compiled out. `list` (or nullptr): big launches run the LEAN kernel below over every block first; it
+// decodes the blocks whose sections are all raw and appends the others' positions to list[1 ..] (list[0] = their number):
+// this kernel then runs with a fixed grid and walks that list.
 extern "C" __global__ void __launch_bounds__(64, WAVES_PER_SIMD)
 zxc_decode_blocks_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
                          uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,
                          uint32_t trailer_bytes, uint8_t* __restrict__ scratch, uint32_t scratch_stride, uint32_t dbg,
                          uint32_t* __restrict__ slot_busy, uint32_t n_slots, const uint32_t* __restrict__ order,
-                         uint32_t cap_override) {
-    decode_one_block<false>(comp, jobs, n_jobs, out, status, block_size, trailer_bytes, scratch, scratch_stride, dbg,
-                            slot_busy, n_slots, order, cap_override, nullptr, 0u, nullptr);
+                         uint32_t cap_override, const uint32_t* __restrict__ list) {
+    // (one call site for both modes: a plain launch has one block per workgroup, grid = n_jobs)
+    const uint32_t n = list ? uni(__hip_atomic_load(list, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : n_jobs;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        decode_one_block<false>(comp, jobs, n_jobs, out, status, block_size, trailer_bytes, scratch, scratch_stride, dbg,
+                                slot_busy, n_slots, order, cap_override, nullptr, 0u, nullptr, list ? uni(list[1u + i]) : i);
+        wave_lds_fence();
+    }
 }
 
 extern "C" __global__ void __launch_bounds__(64, WAVES_PER_SIMD)
@@ -1281,7 +1291,79 @@ zxc_decode_blocks_dict_kernel(const uint8_t* __restrict__ comp, const zxc_dev_jo
                               uint32_t cap_override, const uint8_t* __restrict__ dict, uint32_t dict_size,
                               const uint8_t* __restrict__ dict_huf) {
     decode_one_block<true>(comp, jobs, n_jobs, out, status, block_size, trailer_bytes, scratch, scratch_stride, dbg,
-                           slot_busy, n_slots, order, cap_override, dict, dict_size, dict_huf);
+                           slot_busy, n_slots, order, cap_override, dict, dict_size, dict_huf, blockIdx.x);
+}
+
+// Which kernel decodes a block: the lean one unless it is a GLO block with a coded literal / token section (every other
+// block, malformed ones included, gets its verdict from the lean kernel). ONE predicate for the lean kernel and for the
+// pass that builds the full kernel's list: a block must be taken by exactly one of them.
+__device__ __forceinline__ bool block_needs_full_kernel(const uint8_t* __restrict__ src, uint32_t src_sz) {
+    if (src_sz < 8u + 12u) return false;
+    const uint32_t comp_sz = ld32(src + 3);
+    if (ld8(src) != 1u || comp_sz < 12u || (uint64_t)8u + comp_sz > src_sz) return false;
+    return ld8(src + 16) != 0u || ld8(src + 17) != 0u;
+}
+
+// ------------------------------------------------------------------ the lean kernel
+// One wavefront per block like the full kernel, built for LEAN_WAVES_PER_SIMD waves per SIMD (<= 64 VGPRs, < 5 KiB LDS):
+// RAW blocks and GLO / GHI blocks with raw sections, no checksum, no dictionary. A block it cannot take is appended to
+// `list` for the full kernel (see above) and its status slot is left alone.
+#ifndef LEAN_WAVES_PER_SIMD
+#define LEAN_WAVES_PER_SIMD 6
+#endif
+#include "zxc_seq_lean.inc"
+
+extern "C" __global__ void __launch_bounds__(64, LEAN_WAVES_PER_SIMD)
+zxc_decode_blocks_lean_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
+                              uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,
+                              const uint32_t* __restrict__ order, uint32_t cap_override) {
+    __shared__ LeanLds L;
+    const int lane = threadIdx.x;
+    if (blockIdx.x >= n_jobs) return;
+    const uint32_t b = order ? uni(order[blockIdx.x]) : blockIdx.x;
+    const uint32_t cap = cap_override ? cap_override : block_size + 2112u;
+    const uint64_t comp_off = jobs[b].comp_off;
+    const uint32_t src_sz = uni(jobs[b].comp_size);
+    const uint32_t out_len = uni(jobs[b].out_len);
+    const uint8_t* src = comp + comp_off;
+    uint8_t* dst = out + jobs[b].out_off;
+    int rc;
+    if (uni(block_needs_full_kernel(src, src_sz) ? 1u : 0u)) return;  // on the full kernel's list (zxc_order_scatter_kernel)
+    if (src_sz < 8u) {
+        rc = E_SRC_TOO_SMALL;
+    } else {
+        const uint32_t type = uni(ld8(src));
+        const uint32_t comp_sz = uni(ld32(src + 3));
+        if ((uint64_t)8u + comp_sz > src_sz) {
+            rc = E_SRC_TOO_SMALL;
+        } else if (type == 1u || type == 2u) {
+            rc = decode_lz_block_lean(src + 8, comp_sz, type == 2u, dst, out_len, cap, L, lane);
+        } else if (type == 0u) {  // RAW: stored bytes
+            if (comp_sz > cap) rc = E_DST_TOO_SMALL;
+            else {
+                const uint32_t n = comp_sz < out_len ? comp_sz : out_len;
+                const uint8_t* s8 = src + 8;
+                uint32_t i = 16u * lane;
+                for (; i + 3072u + 16u <= n; i += 4096u) {  // 4 x 1 KiB in flight per wave
+                    const v4u a0 = ld128(s8 + i), a1 = ld128(s8 + i + 1024u), a2 = ld128(s8 + i + 2048u),
+                              a3 = ld128(s8 + i + 3072u);
+                    *(v4u*)(dst + i) = a0;
+                    *(v4u*)(dst + i + 1024u) = a1;
+                    *(v4u*)(dst + i + 2048u) = a2;
+                    *(v4u*)(dst + i + 3072u) = a3;
+                }
+                for (; i + 16u <= n; i += 1024u) *(v4u*)(dst + i) = ld128(s8 + i);
+                const uint32_t tail = n & ~15u;
+                if (tail + (uint32_t)lane < n) dst[tail + lane] = s8[tail + lane];
+                rc = (int)comp_sz;
+            }
+        } else if (type == 255u) {
+            rc = E_CORRUPT;
+        } else {
+            rc = E_BAD_BLOCK_TYPE;
+        }
+    }
+    if (lane == 0) status[b] = rc == ZXC_DEV_DEFER ? ZXC_DEV_E_INTERNAL : rc;  // (DEFER cannot happen: see the predicate)
 }
 
 // ------------------------------------------------------------------ launch order
@@ -1317,7 +1399,8 @@ zxc_order_hist_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __r
 
 extern "C" __global__ void __launch_bounds__(256)
 zxc_order_scatter_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
-                         uint32_t block_size, uint32_t* __restrict__ hist, uint32_t* __restrict__ order) {
+                         uint32_t block_size, uint32_t* __restrict__ hist, uint32_t* __restrict__ order,
+                         uint32_t* __restrict__ list) {
     __shared__ uint32_t cnt[64], base[64];
     if (threadIdx.x < 64u) cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -1334,5 +1417,9 @@ zxc_order_scatter_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* 
         base[threadIdx.x] = cnt[threadIdx.x] ? s + atomicAdd(hist + 64u + threadIdx.x, cnt[threadIdx.x]) : 0u;
     }
     __syncthreads();
-    if (i < n_jobs) order[base[bk] + rank] = i;
+    if (i < n_jobs) {
+        order[base[bk] + rank] = i;
+        // two-pass launches: positions (in launch order) of the blocks the full kernel decodes; list[0] = their number
+        if (list && block_needs_full_kernel(comp + jobs[i].comp_off, jobs[i].comp_size)) list[1u + atomicAdd(list, 1u)] = base[bk] + rank;
+    }
 }

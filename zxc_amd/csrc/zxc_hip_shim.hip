@@ -13,11 +13,14 @@ extern "C" __global__ void zxc_decode_blocks_kernel(const uint8_t* comp, const z
                                                     uint8_t* out, int32_t* status, uint32_t block_size,
                                                     uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride, uint32_t dbg,
                                                     uint32_t* slot_busy, uint32_t n_slots, const uint32_t* order,
-                                                    uint32_t cap_override);
+                                                    uint32_t cap_override, const uint32_t* list);
+extern "C" __global__ void zxc_decode_blocks_lean_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
+                                                         uint8_t* out, int32_t* status, uint32_t block_size,
+                                                         const uint32_t* order, uint32_t cap_override);
 extern "C" __global__ void zxc_order_hist_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                  uint32_t block_size, uint32_t* hist);
 extern "C" __global__ void zxc_order_scatter_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
-                                                    uint32_t block_size, uint32_t* hist, uint32_t* order);
+                                                    uint32_t block_size, uint32_t* hist, uint32_t* order, uint32_t* list);
 extern "C" __global__ void zxc_decode_blocks_dict_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                          uint8_t* out, int32_t* status, uint32_t block_size,
                                                          uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride,
@@ -54,7 +57,7 @@ static struct {
     int wg_per_cu;
     /* launch-order buffers ([128 u32 histogram + cursors | order[n]]), one per stream seen: launches on
      * one stream are ordered, so a stream's buffer is free again when its next launch is enqueued */
-    struct { void* stream; uint32_t* buf; size_t cap; int used; } ord[ZXC_ORDER_STREAMS];
+    struct { void* stream; uint32_t* buf; size_t cap; int used; hipStream_t aux; hipEvent_t fork, join; } ord[ZXC_ORDER_STREAMS];
 } g_dev[ZXC_MAX_DEVICES];
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 
@@ -166,30 +169,48 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
         pool.stride = stride;
     }
     const uint32_t n_slots = pool.n_slots;
-    // Heaviest-first dispatch order once the launch spans more than one round of resident workgroups.
+    // Two kernels for archives without dictionary and checksums: the LEAN kernel (more waves per SIMD, raw sections only)
+    // over every block, and the full kernel over the list of blocks with a coded section, which the launch-order pass builds
+    // from the block headers. The two run side by side: the full kernel on a helper stream forked from the caller's and joined
+    // back into it (event fork / join: capturable, no host synchronisation). Per-stream buffer:
+    // [128 u32 histogram + cursors | list[n + 1] | order[n]]; heaviest-first dispatch order (a launch ends when its slowest
+    // block ends).
+    const bool two_pass = !d_dict && !d_dict_huf && !verify_trailer && !(g_debug_flags & 0x40000000u);
+    const bool want_order = two_pass || (n_jobs > max_slots && !(g_debug_flags & 0x80000000u));
     uint32_t* order = NULL;
-    if (n_jobs > max_slots && !(g_debug_flags & 0x80000000u)) {
-        int k = -1;
+    uint32_t* list = NULL;
+    int k = -1;
+    if (want_order) {
         for (int i = 0; i < ZXC_ORDER_STREAMS; i++)
             if (g_dev[dev].ord[i].used && g_dev[dev].ord[i].stream == stream) k = i;
         for (int i = 0; k < 0 && i < ZXC_ORDER_STREAMS; i++)
             if (!g_dev[dev].ord[i].used) { k = i; g_dev[dev].ord[i].used = 1; g_dev[dev].ord[i].stream = stream; }
-        if (k >= 0) {  // (more distinct streams than buffers: plain order, still correct)
-            const size_t want = 128u + (size_t)n_jobs;
-            if (g_dev[dev].ord[k].cap < want) {
-                if (g_dev[dev].ord[k].buf) (void)hipFree(g_dev[dev].ord[k].buf);
-                g_dev[dev].ord[k].buf = NULL;
-                g_dev[dev].ord[k].cap = 0;
-                if (hipMalloc((void**)&g_dev[dev].ord[k].buf, want * 4u) == hipSuccess) g_dev[dev].ord[k].cap = want;
+        if (k >= 0) {  // (more distinct streams than buffers: one kernel in plain order, still correct)
+            auto& o = g_dev[dev].ord[k];
+            const size_t want = 128u + 2u * (size_t)n_jobs + 1u;
+            if (o.cap < want) {
+                if (o.buf) (void)hipFree(o.buf);
+                o.buf = NULL;
+                o.cap = 0;
+                if (hipMalloc((void**)&o.buf, want * 4u) == hipSuccess) o.cap = want;
             }
-            uint32_t* buf = g_dev[dev].ord[k].buf;
-            if (buf && hipMemsetAsync(buf, 0, 128u * 4u, (hipStream_t)stream) == hipSuccess) {
+            if (two_pass && !o.aux) {
+                if (hipStreamCreateWithFlags(&o.aux, hipStreamNonBlocking) != hipSuccess) o.aux = NULL;
+                else if (hipEventCreateWithFlags(&o.fork, hipEventDisableTiming) != hipSuccess ||
+                         hipEventCreateWithFlags(&o.join, hipEventDisableTiming) != hipSuccess) {
+                    (void)hipStreamDestroy(o.aux);
+                    o.aux = NULL;
+                }
+            }
+            uint32_t* buf = o.buf;
+            if (buf && hipMemsetAsync(buf, 0, 129u * 4u, (hipStream_t)stream) == hipSuccess) {
+                if (two_pass && o.aux) list = buf + 128;
                 const uint32_t g = (n_jobs + 255u) / 256u;
                 hipLaunchKernelGGL(zxc_order_hist_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
                                    d_jobs, n_jobs, block_size, buf);
                 hipLaunchKernelGGL(zxc_order_scatter_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream,
-                                   (const uint8_t*)d_comp, d_jobs, n_jobs, block_size, buf, buf + 128);
-                order = buf + 128;
+                                   (const uint8_t*)d_comp, d_jobs, n_jobs, block_size, buf, buf + 129 + n_jobs, list);
+                order = buf + 129 + n_jobs;
             }
         }
     }
@@ -198,10 +219,24 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
                            (const uint8_t*)d_comp, d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size,
                            verify_trailer ? 4u : 0u, pool.scratch, stride, g_debug_flags, pool.busy, n_slots,
                            order, cap_override, (const uint8_t*)d_dict, dict_size, (const uint8_t*)d_dict_huf);
-    else
+    else if (list) {
+        auto& o = g_dev[dev].ord[k];
+        bool forked = false;
+#ifndef EXP_SKIP_FULL  // (experiment: the lean kernel's own time; the blocks on the list stay undecoded)
+        forked = hipEventRecord(o.fork, (hipStream_t)stream) == hipSuccess && hipStreamWaitEvent(o.aux, o.fork, 0) == hipSuccess;
+        // (if the fork fails the full kernel simply runs behind the lean one on the caller's stream)
+        hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(n_jobs < max_slots ? n_jobs : max_slots), dim3(64), 0,
+                           forked ? o.aux : (hipStream_t)stream, (const uint8_t*)d_comp, d_jobs, n_jobs, (uint8_t*)d_out, d_status,
+                           block_size, 0u, pool.scratch, stride, g_debug_flags, pool.busy, n_slots, order, cap_override, list);
+        if (forked && hipEventRecord(o.join, o.aux) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
+#endif
+        hipLaunchKernelGGL(zxc_decode_blocks_lean_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
+                           d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, order, cap_override);
+        if (forked && hipStreamWaitEvent((hipStream_t)stream, o.join, 0) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
+    } else
         hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
                            d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, verify_trailer ? 4u : 0u,
-                           pool.scratch, stride, g_debug_flags, pool.busy, n_slots, order, cap_override);
+                           pool.scratch, stride, g_debug_flags, pool.busy, n_slots, order, cap_override, (const uint32_t*)NULL);
     return hipGetLastError() == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
 }
 
