@@ -37,6 +37,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         print(f"  per block: big flat nodes {pr[:, 8].mean():.1f} ({pr[:, 9].mean():.0f} steps), big bitmap nodes {pr[:, 10].mean():.1f} "
               f"({pr[:, 11].mean():.0f} words), medium nodes {0:.1f}; blocks {pr.shape[0]}", flush=True)
         sys.exit(0)
+    if os.environ.get("AB_PHASES") == "lean":  # lean kernel built with -DEXP_PHASES: shader clocks per phase in each block's first 64 bytes
+        ph = d_out[:n * 65536].view(-1, 65536)[:, :64].cpu().numpy().view(np.uint32).astype(np.float64)
+        ph = ph[(ph < 5e7).all(axis=1) & (ph[:, 1] > 0)]  # (RAW blocks and blocks of the full kernel: their bytes are data)
+        names = ["loop edge", "tokens + varints", "scans + bounds", "tile cut + errors", "next tokens requested", "ring zeroing / giant", "literal + far requests",
+                 "dependency analysis", "classification", "literal wait + puts", "far wait + puts", "rounds: header + near steps", "rounds: byte loops + whole-wave copies",
+                 "rounds: tail + sparse finish", "final wait + flush", ""]
+        tot = ph.sum()
+        for i, nm in enumerate(names):
+            if nm: print(f"  {nm:40s} {100 * ph[:, i].sum() / tot:5.1f} %   mean {ph[:, i].mean():9.0f} clk/block")
+        print(f"  total mean {ph.sum(axis=1).mean():.0f} clk/block over {ph.shape[0]} blocks", flush=True)
+        sys.exit(0)
     if os.environ.get("AB_PHASES"):  # library built with -DEXP_PHASES: per-phase shader clocks in each block's first 32 bytes
         ph = d_out[:n * 65536].view(-1, 65536)[:, :64].cpu().numpy().view(np.uint32).astype(np.float64)
         ph = ph[(ph < 5e7).all(axis=1)]  # RAW blocks never reach the sequence loop: their bytes are data

@@ -233,7 +233,11 @@ __device__ __forceinline__ void flush_to(RingLds& L, Out& O, uint32_t upto, int 
     for (uint32_t c = O.flushed + 16u * (uint32_t)lane; c < end; c += 1024u) {
         const v4u v = ring_rd128_aligned(L, c);
         if (c + 16u <= O.out_len) {
+#ifdef FLUSH_NT
+            __builtin_nontemporal_store(v, (v4u*)(O.dst + c));
+#else
             *(v4u*)(O.dst + c) = v;  // one coalesced 16 B store per lane
+#endif
         } else if (c < O.out_len) {
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
             for (uint32_t k = 0; c + k < O.out_len; k++) O.dst[c + k] = (uint8_t)(w[k >> 2] >> (8u * (k & 3u)));
