@@ -120,20 +120,6 @@ def open_global_table(all_sizes, block_size, hdr, eof, total_decoded):
     return zxc_amd.Seekable(reader=reader, size=size)
 
 
-def pmc_traffic(args, tiles):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and
-    WRITE_SIZE collected in separate --pmc runs, profiles/<round>_summary.json). NOT measured in this run: a
-    constant that is only reported for the configuration the profile was taken on; otherwise null."""
-    for name in ("r2_summary.json", "r2l7_summary.json"):  # the default workload, the level-7 workload (configs[4])
-        try:
-            summ = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if summ.get("workload") == dict(tiles=tiles, level=args.level, block_size=args.block_size):
-                return summ["hbm_traffic_bytes_per_launch"]["total"], f"profiles/{name}"
-        except Exception:
-            pass
-    return None, None
-
-
 def cpu_baseline(comp, total, budget_s=12.0):
     """The reference's own parallel seekable decode on this box's host cores (bounded sample)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -168,25 +154,23 @@ def cpu_baseline(comp, total, budget_s=12.0):
             "sample": f"oracle C restatement, first {n >> 20} MiB, 1 thread"}
 
 
-def main_encode(args):
-    """configs[2]: per-block LZ77 hash-chain match finding + GLO serialisation on the device over 1 GiB of unique
+def encode_run(args, level, enc_mib, steps, warmup, comm, with_cpu_baseline=True):
+    """configs[2]: per-block LZ77 hash-chain match finding + GLO serialisation on the device over enc_mib MiB of unique
     enwik-like text per GPU, source resident in HBM, compressed blocks left in HBM. value = source GB/s. The
     compressed stream of the LAST timed launch is round-tripped: every block decoded on the device and compared
-    with the source (all of it), and a 64 MiB sample decoded by the unmodified reference decoder on the host."""
+    with the source (all of it), and a 64 MiB sample decoded by the unmodified reference decoder on the host.
+    -> the result line (a dict) on rank 0, None elsewhere."""
     import multiprocessing as mp
-    world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    pool = mp.get_context("spawn").Pool(max(1, min(32, (os.cpu_count() or 1) // world_env)))
     import torch
     import zxc_amd
     from zxc_amd import corpus
-    rank, world, local, backend, dist = init_ranks()
-    torch.cuda.set_device(local)
+    rank, world, local, backend, dist = comm
+    pool = mp.get_context("spawn").Pool(max(1, min(32, (os.cpu_count() or 1) // world)))
     L = zxc_amd.lib()
-    L.zxc_mi355x_set_device(local)
     L.zxc_mi355x_gather_blocks_device.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     dev = torch.device("cuda", local)
     bs = args.block_size
-    n = args.enc_mib << 20
+    n = enc_mib << 20
     t0 = time.time()
     parts = pool.map(corpus.gen_chunk, corpus.enwik_chunks(n, seed=1 + rank))
     pool.close()
@@ -202,21 +186,21 @@ def main_encode(args):
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        rc = L.zxc_mi355x_encode_blocks_device(C.c_void_p(d_src.data_ptr()), n, bs, args.level, 0,
+        rc = L.zxc_mi355x_encode_blocks_device(C.c_void_p(d_src.data_ptr()), n, bs, level, 0,
                                                C.c_void_p(d_slots.data_ptr()), C.c_void_p(d_sizes.data_ptr()),
                                                C.c_void_p(stream))
         assert rc == 0, rc
 
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
     ev[0].record()
-    for i in range(args.steps):
+    for i in range(steps):
         step()
         ev[i + 1].record()
     torch.cuda.synchronize()
@@ -249,7 +233,7 @@ def main_encode(args):
     import oracle_py
     ref_ok = None
     if oracle_py.Ref.available():  # the unmodified reference decoder accepts the stream (host API: same kernels + framing)
-        comp = zxc_amd.compress(sample, args.level, bs, True)
+        comp = zxc_amd.compress(sample, level, bs, True)
         rc, out = oracle_py.Ref().decompress(comp, len(sample))
         assert rc == len(sample) and out == sample, "reference decoder rejects the encoder's archive"
         ref_ok = f"{len(sample) >> 20} MiB archive decoded bit-exact by the unmodified reference decoder"
@@ -257,28 +241,27 @@ def main_encode(args):
         t = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
-    if rank == 0:
-        kern_s = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)])) / 1e3
-        algo = n + csize
-        entry = {1: "l1", 2: "l2", 3: "l34", 4: "l34"}.get(args.level, "l57")
-        line = {
-            "metric": f"device LZ77 hash-chain encode GB/s of source (level {args.level}, enwik-like text, {bs >> 10} KiB blocks, HBM-resident in/out)",
-            "value": round(world * n * args.steps / wall / 1e9, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"configs[2]: {args.enc_mib} MiB of unique enwik-like text per GPU (synth chunks of 8 MiB, own seed "
-                                   f"each), level {args.level}, {bs >> 10} KiB blocks, one wavefront per block", "blocks_per_gpu": nb,
-                       "ratio": round(n / csize, 3), "parallelism": f"block-range x{world}, no collectives", "prep_s": prep_s},
-            "roofline": {"bound": "hbm", "achieved": round(algo / kern_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(algo / kern_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": f"zxc_encode_blocks_kernel_{entry}", "avg_launch_ms": round(kern_s * 1e3, 4),
-                         "algorithmic_bytes_per_launch": algo},
-            "round_trip": {"device": f"all {nb} blocks decoded on the device == source", "reference": ref_ok}}
-        if not args.no_cpu_baseline and world == 1 and oracle_py.Ref.available():
-            line["cpu_baseline"] = cpu_baseline_encode(sample, args.level, bs)
-        print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    kern_s = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)])) / 1e3
+    algo = n + csize
+    entry = {1: "l1", 2: "l2", 3: "l34", 4: "l34"}.get(level, "l57")
+    line = {
+        "metric": f"device LZ77 hash-chain encode GB/s of source (level {level}, enwik-like text, {bs >> 10} KiB blocks, HBM-resident in/out)",
+        "value": round(world * n * steps / wall / 1e9, 2), "unit": "GB/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": round(wall / steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"configs[2]: {enc_mib} MiB of unique enwik-like text per GPU (synth chunks of 8 MiB, own seed "
+                               f"each), level {level}, {bs >> 10} KiB blocks, one wavefront per block", "blocks_per_gpu": nb,
+                   "ratio": round(n / csize, 3), "parallelism": f"block-range x{world}, no collectives", "prep_s": prep_s},
+        "roofline": {"bound": "hbm", "achieved": round(algo / kern_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(algo / kern_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": profiled_traffic("encode_l%d" % level, enc_mib=enc_mib),
+                     "kernel": f"zxc_encode_blocks_kernel_{entry}", "avg_launch_ms": round(kern_s * 1e3, 4),
+                     "algorithmic_bytes_per_launch": algo},
+        "round_trip": {"device": f"all {nb} blocks decoded on the device == source", "reference": ref_ok}}
+    if with_cpu_baseline and world == 1 and oracle_py.Ref.available():
+        line["cpu_baseline"] = cpu_baseline_encode(sample, level, bs)
+    return line
 
 
 def cpu_baseline_encode(sample, level, bs):
@@ -328,7 +311,7 @@ def calibration_launch(dev, bs, n=16384):
     return {"dispatch": "first zxc_decode_blocks_kernel launch", "read_bytes": n * (bs + 8), "write_bytes": n * bs}
 
 
-def init_ranks():
+def init_ranks(cpu=False):
     """(rank, world, local device, backend, dist or None). One process per GPU; the driver launches N > 1 through
     torch.distributed.run. ZXC_BENCH_BACKEND=gloo + ZXC_BENCH_DEVICE=0 rehearses the N-rank path on one GPU."""
     import torch
@@ -339,7 +322,7 @@ def init_ranks():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        if backend == "nccl":
+        if backend == "nccl" and not cpu:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
@@ -355,47 +338,22 @@ def rank_partition(rank, world, tiles_per_gpu, block_size):
     return n_total, first, last
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--tiles", type=int, default=int(os.environ.get("ZXC_BENCH_TILES", "41")),
-                    help="corpus tiles per GPU, 211 943 424 B of unique silesia-mix plaintext each (41 = 8.7 GB decoded / "
-                         "4.4 GB compressed per GPU = configs[3]'s 64 GiB over 8 GPUs; levels 6-7: pass --tiles 4, the "
-                         "reference encoder prepares them at ~8 MB/s per thread)")
-    ap.add_argument("--enc-mib", type=int, default=1024, help="(encode mode) MiB of unique enwik-like text per GPU (configs[2]: 1 GiB)")
-    ap.add_argument("--level", type=int, default=3)
-    ap.add_argument("--block-size", type=int, default=65536)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--checksum", action="store_true",
-                    help="archives carry per-block rapidhash trailers and every launch verifies them on the device")
-    ap.add_argument("--calib", action="store_true",
-                    help="(tools/profile.sh) first launch = a RAW-only archive of known size: 16 B/lane streaming reads "
-                         "and writes of known byte counts in the same counter pass, to calibrate FETCH_SIZE / WRITE_SIZE")
-    ap.add_argument("--mode", choices=("decode", "encode"), default="decode",
-                    help="decode = the headline metric (BASELINE.json configs[1]; --level 7 gives configs[4]); "
-                         "encode = configs[2]: device match finder + serialiser over enwik-like text, GB/s of source")
-    args = ap.parse_args()
-    if args.mode == "encode":
-        return main_encode(args)
-
+def decode_run(args, level, tiles, steps, warmup, comm, checksum=False, calib_launch=False, with_cpu_baseline=True,
+               cpu_budget_s=12.0):
+    """One decode measurement: this rank's block range of ONE corpus of world x tiles tiles, `steps` timed launches
+    bracketed by barrier + synchronize, every byte and status checked before and after. -> the result line on rank 0."""
     import multiprocessing as mp
-    world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    # generator processes first, before anything touches HIP (numpy only; spawn keeps them free of torch state)
-    pool = mp.get_context("spawn").Pool(max(1, min(32, (os.cpu_count() or 1) // world_env)))
-
     import torch
     import zxc_amd
-    rank, world, local, backend, dist = init_ranks()
-    torch.cuda.set_device(local)
-    zxc_amd.lib().zxc_mi355x_set_device(local)
+    rank, world, local, backend, dist = comm
+    # generator processes (numpy only; spawn keeps them free of torch state)
+    pool = mp.get_context("spawn").Pool(max(1, min(48, (os.cpu_count() or 1) // world)))
     dev = torch.device("cuda", local)
     bs = args.block_size
 
     # ---- workload: this rank's block range of the one corpus
-    n_total, first, last = rank_partition(rank, world, args.tiles, bs)
-    d_comp, my_sizes, d_want, hdr, eof, prep, tile0_comp = build_rank_corpus(first, last, args.level, bs, pool, dev, args.checksum)
+    n_total, first, last = rank_partition(rank, world, tiles, bs)
+    d_comp, my_sizes, d_want, hdr, eof, prep, tile0_comp = build_rank_corpus(first, last, level, bs, pool, dev, checksum)
     pool.close()
     if world > 1:  # control plane only: every rank learns the whole seek table (4 B per block)
         gathered = [None] * world
@@ -419,16 +377,16 @@ def main():
 
     def step():
         zxc_amd.decode_blocks_device(d_comp.data_ptr(), d_jobs.data_ptr(), n_jobs, d_out.data_ptr(),
-                                     d_status.data_ptr(), bs, args.checksum, stream)
+                                     d_status.data_ptr(), bs, checksum, stream)
 
     def check(when):
         assert torch.equal(d_status, want_status), f"{when}: block status mismatch on rank {rank}"
         assert torch.equal(d_out[:out_bytes], d_want), f"{when}: decoded bytes differ from the corpus on rank {rank}"
 
     calib = None
-    if args.calib:
+    if calib_launch:
         calib = calibration_launch(dev, bs)
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         step()
     torch.cuda.synchronize()
     check("before timing")  # bit-exactness of what is being timed: every block's status and every byte
@@ -436,17 +394,17 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
     ev[0].record()
-    for i in range(args.steps):
+    for i in range(steps):
         step()
         ev[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     wall = time.perf_counter() - t0
-    kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+    kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
     d_out.zero_()
     d_status.fill_(-999)
     step()
@@ -461,43 +419,174 @@ def main():
         total_out = int(t[1].item())
     else:
         total_out = out_bytes
-
-    if rank == 0:
-        avg_kernel_s = float(np.mean(kern_ms)) / 1e3
-        value = total_out * args.steps / wall / 1e9
-        achieved = algo_bytes / avg_kernel_s / 1e9
-        cfg = "configs[4]" if args.level == 7 else "configs[1]" if args.level == 3 else f"configs[1] at level {args.level}"
-        if world > 1:
-            cfg = f"configs[3] ({world * args.tiles * 211943424 / 2**30:.1f} GiB corpus over {world} GPUs)"
-        traffic, traffic_file = pmc_traffic(args, args.tiles)
-        line = {
-            "metric": f"seekable decode GB/s (level {args.level}, {bs >> 10} KiB independent blocks, HBM-resident in/out"
-                      + (", per-block checksums verified on the device)" if args.checksum else ")"),
-            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{cfg}: ONE seekable corpus of {world * args.tiles} tiles x 211943424 B ({prep['source']}), "
-                                   f"level {args.level}, {bs >> 10} KiB blocks, {n_total} blocks in one seek table; rank g decodes "
-                                   f"blocks [g*N//G, (g+1)*N//G) (rank 0: [{first}, {last})), one wavefront per block",
-                       "blocks_per_gpu": n_jobs, "decoded_bytes_per_gpu": out_bytes,
-                       "compressed_bytes_per_gpu": algo_bytes - out_bytes,
-                       "ratio": round(out_bytes / (algo_bytes - out_bytes), 3),
-                       "parallelism": f"seek-table block range x{world}, no collectives on the data path", "prep": prep},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": f"{traffic_file} (rocprofv3 PMC passes of this command), not this run"
-                                           if traffic else None,
-                         "kernel": "zxc_decode_blocks_kernel", "avg_launch_ms": round(avg_kernel_s * 1e3, 4),
-                         "algorithmic_bytes_per_launch": algo_bytes},
-            "bit_exact": "every byte and block status checked before and after the timed loop",
-        }
-        if calib:
-            line["calibration"] = calib
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(tile0_comp, int.from_bytes(tile0_comp[-12:-4], "little"))
-        print(json.dumps(line))
+    if rank != 0:
+        return None
+    avg_kernel_s = float(np.mean(kern_ms)) / 1e3
+    value = total_out * steps / wall / 1e9
+    achieved = algo_bytes / avg_kernel_s / 1e9
+    cfg = "configs[4]" if level == 7 else "configs[1]" if level == 3 else f"configs[1] at level {level}"
     if world > 1:
-        dist.destroy_process_group()
+        cfg = f"configs[3] ({world * tiles * 211943424 / 2**30:.1f} GiB corpus over {world} GPUs)"
+    traffic = profiled_traffic("decode_l%d" % level, tiles=tiles, block_size=bs) if not checksum else None
+    line = {
+        "metric": f"seekable decode GB/s (level {level}, {bs >> 10} KiB independent blocks, HBM-resident in/out"
+                  + (", per-block checksums verified on the device)" if checksum else ")"),
+        "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(wall / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"{cfg}: ONE seekable corpus of {world * tiles} tiles x 211943424 B ({prep['source']}), "
+                               f"level {level}, {bs >> 10} KiB blocks, {n_total} blocks in one seek table; rank g decodes "
+                               f"blocks [g*N//G, (g+1)*N//G) (rank 0: [{first}, {last})), one wavefront per block",
+                   "blocks_per_gpu": n_jobs, "decoded_bytes_per_gpu": out_bytes,
+                   "compressed_bytes_per_gpu": algo_bytes - out_bytes,
+                   "ratio": round(out_bytes / (algo_bytes - out_bytes), 3),
+                   "parallelism": f"seek-table block range x{world}, no collectives on the data path", "prep": prep},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "kernel": "zxc_decode_blocks_lean_kernel + zxc_decode_blocks_kernel (coded sections), side by side"
+                               if level <= 5 and not checksum else "zxc_decode_blocks_kernel",
+                     "avg_launch_ms": round(avg_kernel_s * 1e3, 4), "algorithmic_bytes_per_launch": algo_bytes},
+        "bit_exact": "every byte and block status checked before and after the timed loop",
+    }
+    if calib:
+        line["calibration"] = calib
+    if with_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline(tile0_comp, int.from_bytes(tile0_comp[-12:-4], "little"), cpu_budget_s)
+    del d_comp, d_want, d_out
+    torch.cuda.empty_cache()
+    return line
+
+
+def profiled_traffic(what, **workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (FETCH_SIZE / WRITE_SIZE in
+    separate --pmc runs, counters corrected as profiles/r3_gather_calibration.log prescribes). NOT measured in this run: a
+    constant reported only when the run's workload equals the profiled one (the object says which file), else null."""
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "r3_traffic.json")))
+        e = tab.get(what)
+        if e and all(e["workload"].get(k) == v for k, v in workload.items()):
+            return {"bytes_per_launch": e["bytes_per_launch"], "read": e["read"], "write": e["write"], "source": e["source"],
+                    "measured_in_this_run": False}
+    except Exception:
+        pass
+    return None
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks of this script through torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1) and hand their exit code back — never a silent one-GPU run."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def rehearse(args, comm):
+    """The N-rank path without a GPU (tests/test_sharding_cpu.py): gloo ranks on CPU tensors go through every step of
+    decode_run except the device launch — partition, reference-encoded tiles of the range, all_gather of the seek-table
+    entries, ONE table through zxc_seekable_open_reader, zxc_mi355x_plan_seekable — and the oracle (the checker) decodes
+    each rank's jobs from its own compressed span."""
+    import torch
+    from zxc_amd import corpus
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    rank, world, local, backend, dist = comm
+    corpus.TILE_BYTES = 5 * 65536
+    corpus.CHUNK_BYTES = 2 * 65536
+    bs = 65536
+    n_total, first, last = rank_partition(rank, world, args.tiles, bs)
+    d_comp, my_sizes, d_want, hdr, eof, prep, _ = build_rank_corpus(first, last, args.level, bs, None, torch.device("cpu"))
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, my_sizes.tobytes())
+        all_sizes = np.concatenate([np.frombuffer(b, dtype=np.uint32) for b in gathered])
+    else:
+        all_sizes = my_sizes
+    s = open_global_table(all_sizes, bs, hdr, eof, n_total * bs)
+    jobs = s.plan(first, last - first, 16 + int(all_sizes[:first].astype(np.int64).sum()))
+    comp = d_comp.numpy().tobytes()
+    o = oracle_py.Oracle()
+    out = bytearray()
+    for j in jobs:
+        rc, b = o.decode_block(comp[int(j["comp_off"]):int(j["comp_off"]) + int(j["comp_size"])], bs)
+        assert rc == int(j["out_len"])
+        out += b
+    assert bytes(out) == d_want.numpy().tobytes()
+    t = torch.tensor([float(len(out))], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"metric": "rehearsal of the N-rank launch path on CPU tensors (no device launch, nothing timed)", "value": 0.0,
+                          "unit": "GB/s", "n_gpus": world, "rehearsal": True, "blocks_total": n_total, "blocks_rank0": [first, last],
+                          "decoded_bytes_all_ranks": int(t.item()), "checker": "oracle decode of every rank's jobs == corpus"}))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tiles", type=int, default=int(os.environ.get("ZXC_BENCH_TILES", "41")),
+                    help="corpus tiles per GPU, 211 943 424 B of unique silesia-mix plaintext each (41 = 8.7 GB decoded / "
+                         "4.4 GB compressed per GPU = configs[3]'s 64 GiB over 8 GPUs)")
+    ap.add_argument("--enc-mib", type=int, default=1024, help="MiB of unique enwik-like text per GPU for the encoder workload (configs[2]: 1 GiB)")
+    ap.add_argument("--l7-tiles", type=int, default=10, help="corpus tiles of the level-7 line of the default run (configs[4])")
+    ap.add_argument("--level", type=int, default=3)
+    ap.add_argument("--block-size", type=int, default=65536)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default run only: skip the level-7 decode (configs[4]) and level-3 encode (configs[2]) lines")
+    ap.add_argument("--checksum", action="store_true",
+                    help="archives carry per-block rapidhash trailers and every launch verifies them on the device")
+    ap.add_argument("--calib", action="store_true",
+                    help="(tools/profile.sh) first launch = a RAW-only archive of known size: 16 B/lane streaming reads "
+                         "and writes of known byte counts in the same counter pass, to calibrate FETCH_SIZE / WRITE_SIZE")
+    ap.add_argument("--mode", choices=("decode", "encode"), default="decode",
+                    help="decode = the headline metric (BASELINE.json configs[1]; --level 7 gives configs[4]); "
+                         "encode = configs[2]: device match finder + serialiser over enwik-like text, GB/s of source")
+    ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the N-rank launch path (gloo, no device launch)")
+    args = ap.parse_args()
+    if args.rehearse:
+        os.environ.setdefault("ZXC_BENCH_BACKEND", "gloo")
+    # --gpus N is the contract: N ranks, one per GPU. Under a launcher WORLD_SIZE must agree with it; without one this
+    # process starts the ranks itself.
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
+
+    if args.rehearse:
+        comm = init_ranks(cpu=True)
+        rehearse(args, comm)
+    else:
+        import torch
+        import zxc_amd
+        comm = init_ranks()
+        rank, world, local, backend, dist = comm
+        torch.cuda.set_device(local)
+        zxc_amd.lib().zxc_mi355x_set_device(local)
+        if args.mode == "encode":
+            line = encode_run(args, args.level, args.enc_mib, args.steps, args.warmup, comm, not args.no_cpu_baseline)
+        else:
+            line = decode_run(args, args.level, args.tiles, args.steps, args.warmup, comm, args.checksum, args.calib,
+                              not args.no_cpu_baseline)
+            # The default single-GPU run also measures the other two single-GPU configurations of BASELINE.json, each with its
+            # own roofline / cpu_baseline objects and its own bit-exactness check (VERDICT r2: next #2).
+            if world == 1 and args.level == 3 and not args.checksum and not args.calib and not args.no_secondary:
+                sec = {}
+                sec["level7"] = decode_run(args, 7, args.l7_tiles, max(5, args.steps // 2), 2, comm,
+                                           with_cpu_baseline=not args.no_cpu_baseline, cpu_budget_s=6.0)
+                sec["encode_l3"] = encode_run(args, 3, args.enc_mib, max(3, args.steps // 4), 1, comm, not args.no_cpu_baseline)
+                line["secondary"] = sec
+        if rank == 0:
+            print(json.dumps(line))
+    if comm[4] is not None:
+        comm[4].destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -22,9 +22,11 @@ ZXC_EXPORT const char* zxc_version_string(void);
 ZXC_EXPORT uint64_t zxc_compress_bound(const size_t input_size);
 
 /* reference include/zxc_buffer.h:119 (impl src/lib/zxc_dispatch.c:658-818). Whole-buffer
- * compress into a v8 archive (optionally seekable). Blocks are encoded on the GPU by one
- * match-finding strategy whatever the level (valid, reference-decodable output; sizes differ
- * from the CPU encoder's). Returns archive size or a negative zxc_error_t. */
+ * compress into a v8 archive (optionally seekable). Blocks are encoded on the GPU by a per-level hash-chain match
+ * finder (depth / sufficient length / lazy probes per level: zxc_amd/csrc/zxc_encode_levels.h; GHI blocks at levels
+ * 1-2, GLO above, PivCo-coded sections at levels 6-7, opts->dict seeds every block's tables). The output is a valid
+ * archive the unmodified reference decodes; its bytes differ from the CPU encoder's (another parse). Returns archive
+ * size or a negative zxc_error_t. */
 ZXC_EXPORT int64_t zxc_compress(const void* src, const size_t src_size, void* dst,
                                 const size_t dst_capacity, const zxc_compress_opts_t* opts);
 
@@ -53,8 +55,12 @@ typedef struct zxc_cctx_s zxc_cctx; /* reference include/zxc_buffer.h:236 */
 typedef struct zxc_dctx_s zxc_dctx; /* :238 */
 ZXC_EXPORT uint64_t zxc_compress_block_bound(size_t input_size);              /* :255  8 + n + 68 + 4, 0 if n = 0 or > 2 MiB */
 ZXC_EXPORT uint64_t zxc_decompress_block_bound(const size_t uncompressed_size); /* :272  n + 2112, 0 if n > 2 MiB */
-/* :300  header(8) + payload [+ checksum(4)]; only level, block_size and checksum_enabled of opts are used
- * (a dictionary returns ZXC_ERROR_GPU_UNSUPPORTED) */
+/* :382  estimated peak working memory of one zxc_compress_block call (here: device memory of the staging arena) */
+ZXC_EXPORT uint64_t zxc_estimate_cctx_size(size_t src_size, int level);
+/* :300  header(8) + payload [+ checksum(4)]; level, block_size, checksum_enabled and dict / dict_size of opts are used
+ * (a dictionary seeds the block's match-finder tables, reference src/lib/zxc_dispatch.c:1688-1697). The context's sticky
+ * block size is the caller's block_size, not the reference's dictionary-padded effective size (:1650): nothing outside
+ * the context can observe it. */
 ZXC_EXPORT int64_t zxc_compress_block(zxc_cctx* cctx, const void* src, size_t src_size, void* dst,
                                       size_t dst_capacity, const zxc_compress_opts_t* opts);
 /* :328  dst_capacity in [decoded size, 2 MiB + 2112]; decodes with capacity block_size_ceil(dst_capacity) + 2112 */

@@ -44,6 +44,11 @@ ZXC_EXPORT void zxc_mi355x_free(void* d_ptr);
 ZXC_EXPORT int zxc_mi355x_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 ZXC_EXPORT int zxc_mi355x_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
 ZXC_EXPORT int zxc_mi355x_synchronize(void* stream);
+/* Gives back the device memory the library keeps between calls (staging arenas of the host API that nobody is using;
+ * on the calling thread's device also the section decoders' scratch pools and the launch-order buffers). Call it when
+ * no launch of this library is in flight on that device. Arenas are bounded anyway: every host entry point works in
+ * batches of 256 MiB of output, and a buffer that grew past 768 MiB is freed when its call ends. */
+ZXC_EXPORT void zxc_mi355x_release_cached(void);
 
 /* Fill jobs[0..n_blocks) for blocks [first_block, first_block + n_blocks) of an open
  * seekable archive. Block i's compressed bytes are expected at

@@ -1,0 +1,50 @@
+/* subset_main.c — runs the reference's own unit-test functions (compiled in place from /root/reference/tests/*.c, see the
+ * Makefile) against libzxc_mi355x.so. Test infrastructure. The case list is the public-API part of the reference's table
+ * (tests/test_main.c:60-64 Block API, :50-58 Buffer API, :66-69 contexts, :144-172 seekable); each function returns 1 on
+ * success like there. Usage: zxc_unit_subset [--list] [name-substring]. Prints "RESULT name PASS|FAIL" per case. */
+#include <stdio.h>
+#include <string.h>
+#include "test_common.h"
+
+typedef int (*test_fn_t)(void);
+typedef struct { const char* name; test_fn_t fn; } test_entry_t;
+static const test_entry_t g_tests[] = {
+    TEST_CASE(test_buffer_api), TEST_CASE(test_buffer_api_scratch_buf), TEST_CASE(test_buffer_error_codes),
+    TEST_CASE(test_decompress_inplace), TEST_CASE(test_get_decompressed_size), TEST_CASE(test_decompress_fast_vs_safe_path),
+    TEST_CASE(test_max_compressed_size_logic), TEST_CASE(test_decompress_empty_frame_null_dst),
+    TEST_CASE(test_block_api), TEST_CASE(test_block_api_boundary_sizes), TEST_CASE(test_block_api_large_block_varint),
+    TEST_CASE(test_decompress_block_bound), TEST_CASE(test_decompress_block_safe),
+    TEST_CASE(test_opaque_context_api), TEST_CASE(test_cctx_level_raise_reinit), TEST_CASE(test_estimate_cctx_size),
+    TEST_CASE(test_error_name), TEST_CASE(test_library_info_api),
+    TEST_CASE(test_seekable_table_sizes), TEST_CASE(test_seekable_table_write), TEST_CASE(test_seekable_roundtrip),
+    TEST_CASE(test_seekable_open_query), TEST_CASE(test_seekable_random_access), TEST_CASE(test_seekable_non_seekable_reject),
+    TEST_CASE(test_seekable_single_block), TEST_CASE(test_seekable_all_levels), TEST_CASE(test_seekable_many_blocks),
+    TEST_CASE(test_seekable_open_file), TEST_CASE(test_seekable_open_reader),
+    TEST_CASE(test_seekable_mt_roundtrip), TEST_CASE(test_seekable_mt_single_block), TEST_CASE(test_seekable_mt_random_access),
+    TEST_CASE(test_seekable_mt_full_file), TEST_CASE(test_seekable_open_reader_mt),
+    TEST_CASE(test_seekable_cross_boundary), TEST_CASE(test_seekable_truncated_input), TEST_CASE(test_seekable_corrupted_sek),
+    TEST_CASE(test_seekable_range_out_of_bounds), TEST_CASE(test_seekable_dst_too_small), TEST_CASE(test_seekable_empty_file),
+    TEST_CASE(test_seekable_no_checksum), TEST_CASE(test_seekable_with_checksum), TEST_CASE(test_seekable_work_buf_tail_pad),
+};
+
+int main(int argc, char** argv) {
+    zxc_test_srand(42); /* the reference's fixed seed (tests/test_main.c:200) */
+    const char* filter = NULL;
+    const size_t n = sizeof(g_tests) / sizeof(g_tests[0]);
+    if (argc > 1 && strcmp(argv[1], "--list") == 0) {
+        for (size_t i = 0; i < n; i++) printf("%s\n", g_tests[i].name);
+        return 0;
+    }
+    if (argc > 1) filter = argv[1];
+    int failed = 0, ran = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (filter && !strstr(g_tests[i].name, filter)) continue;
+        const int ok = g_tests[i].fn();
+        printf("RESULT %s %s\n", g_tests[i].name, ok ? "PASS" : "FAIL");
+        fflush(stdout);
+        ran++;
+        failed += !ok;
+    }
+    printf("SUMMARY ran %d failed %d\n", ran, failed);
+    return failed != 0;
+}

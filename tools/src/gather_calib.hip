@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef v4u __attribute__((aligned(1))) v4u_unaligned;
@@ -64,17 +65,20 @@ static void time_it(const char* name, K kern, const uint8_t* buf, uint64_t bytes
     hipEventDestroy(a); hipEventDestroy(b);
 }
 
-int main() {
-    const uint64_t bytes = 2ull << 30;
+int main(int argc, char** argv) {
+    const uint64_t bytes = argc > 1 ? (uint64_t)atoll(argv[1]) << 20 : 2ull << 30;  // buffer size in MiB (default 2 GiB, far beyond the 256 MiB Infinity Cache)
     uint8_t* buf; uint32_t* out;
     if (hipMalloc(&buf, bytes) != hipSuccess || hipMalloc(&out, 64) != hipSuccess) { printf("alloc failed\n"); return 1; }
     hipMemset(buf, 1, bytes);
     hipDeviceSynchronize();
     const int grid = 256 * 32;  // 8 waves per SIMD
     // stream: 2 GiB = 134 217 728 lane-loads of 16 B = 16 reps of 8 388 608 threads... grid*256 = 2 097 152 threads -> 64 reps
+    printf("buffer %llu MiB\n", (unsigned long long)(bytes >> 20));
+    for (int rep = 0; rep < 2; rep++) {
     time_it("stream16", stream16, buf, bytes, out, grid, 64, 0.25, 0.125, 16.0);
     time_it("gather16_in64", gather16_in64, buf, bytes, out, grid, 16, 1.0, 1.0, 16.0);
     time_it("gather16_any", gather16_any, buf, bytes, out, grid, 16, 1.0 + 15.0 / 64.0, 1.0 + 15.0 / 128.0, 16.0);
     time_it("gather32_any", gather32_any, buf, bytes, out, grid, 16, 1.0 + 31.0 / 64.0, 1.0 + 31.0 / 128.0, 32.0);
+    }
     return 0;
 }

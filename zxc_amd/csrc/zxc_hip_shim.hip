@@ -115,6 +115,57 @@ int zxc_mi355x_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes) {
     return hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
 }
 
+/* internal to the library (hidden): a worker thread's own stream and the copies on it (zxc_host.c) */
+int zxc_hip_stream_create(void** stream_out) {
+    hipStream_t st = NULL;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
+    *stream_out = (void*)st;
+    return ZXC_OK;
+}
+void zxc_hip_stream_destroy(void* stream) {
+    if (!stream) return;
+    const int dev = current_device();
+    if (dev >= 0) {  // the launch-order buffer (and helper stream) this stream used is free for another one
+        pthread_mutex_lock(&g_lock);
+        for (int i = 0; i < ZXC_ORDER_STREAMS; i++)
+            if (g_dev[dev].ord[i].used && g_dev[dev].ord[i].stream == stream) { g_dev[dev].ord[i].used = 0; g_dev[dev].ord[i].stream = NULL; }
+        pthread_mutex_unlock(&g_lock);
+    }
+    (void)hipStreamDestroy((hipStream_t)stream);
+}
+int zxc_hip_memcpy_h2d_async(void* d_dst, const void* h_src, size_t bytes, void* stream) {
+    if (bytes == 0) return ZXC_OK;
+    return hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream) == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
+}
+int zxc_hip_memcpy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void* stream) {
+    if (bytes == 0) return ZXC_OK;
+    return hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
+}
+
+extern "C" void zxc_host_release_arenas(void);
+/* Gives back the device memory this library keeps between calls: the host API's staging arenas (those nobody is using)
+ * and, on the calling thread's device, the scratch pools of the section decoders and the launch-order buffers. Call it
+ * when no launch of this library is in flight on that device (pools and order buffers belong to launches). */
+void zxc_mi355x_release_cached(void) {
+    zxc_host_release_arenas();
+    const int dev = current_device();
+    if (dev < 0) return;
+    (void)hipDeviceSynchronize();
+    pthread_mutex_lock(&g_lock);
+    for (int i = 0; i < ZXC_POOLS; i++) {
+        auto& p = g_dev[dev].pool[i];
+        if (p.scratch) (void)hipFree(p.scratch);
+        if (p.busy) (void)hipFree(p.busy);
+        p.scratch = NULL; p.busy = NULL; p.n_slots = 0; p.stride = 0;
+    }
+    for (int i = 0; i < ZXC_ORDER_STREAMS; i++) {
+        auto& o = g_dev[dev].ord[i];
+        if (o.buf) (void)hipFree(o.buf);
+        o.buf = NULL; o.cap = 0;
+    }
+    pthread_mutex_unlock(&g_lock);
+}
+
 int zxc_mi355x_synchronize(void* stream) {
     return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
 }

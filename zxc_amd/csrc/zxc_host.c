@@ -269,10 +269,19 @@ int zxc_hip_decode_blocks(const void* d_comp, const zxc_dev_job_t* d_jobs, uint3
                           const void* d_dict_huf, uint32_t cap_override, void* stream);
 int zxc_hip_current_device(void);
 
-/* Per-device staging arena: the device buffers of the host API live across calls (grown on demand,
- * never shrunk), so a call costs its copies and its launch, not four hipMalloc + hipFree (which
- * synchronise the device). One call at a time per device uses the arena; its mutex is held from
- * run_jobs() until dev_bufs_free(). */
+/* hidden entry points of zxc_hip_shim.hip: a worker's own stream */
+int zxc_hip_stream_create(void** stream_out);
+void zxc_hip_stream_destroy(void* stream);
+int zxc_hip_memcpy_h2d_async(void* d_dst, const void* h_src, size_t bytes, void* stream);
+int zxc_hip_memcpy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void* stream);
+
+/* Staging arenas: the device buffers of the host API live across calls (grown on demand), so a call costs its copies
+ * and its launch, not four hipMalloc + hipFree (which synchronise the device). One call at a time uses an arena; its
+ * mutex is held from run_jobs() until dev_bufs_free(). Every device has ARENA_SUBS of them: sub 0 serves the
+ * single-threaded API, the workers of zxc_seekable_decompress_range_mt take one each (two workers on one device run on
+ * two streams side by side). Every caller batches its work (HOST_BATCH_BYTES of output slots per launch), so an arena
+ * stays within a few hundred MiB; a buffer that grew beyond ARENA_KEEP_MAX is given back when the call ends, and
+ * zxc_mi355x_release_cached() frees everything that is not in use. */
 typedef struct { void* p; size_t cap; } dbuf_t;
 enum { AR_COMP = 0, AR_JOBS, AR_OUT, AR_STATUS, AR_DICT, AR_N };
 typedef struct {
@@ -280,10 +289,13 @@ typedef struct {
     dbuf_t buf[AR_N];
 } arena_t;
 #define HOST_MAX_DEVICES 16
-static arena_t g_arena[HOST_MAX_DEVICES];
+#define ARENA_SUBS 4
+#define ARENA_KEEP_MAX ((size_t)768 << 20)
+static arena_t g_arena[HOST_MAX_DEVICES][ARENA_SUBS];
 static pthread_once_t g_arena_once = PTHREAD_ONCE_INIT;
 static void arena_init_all(void) {
-    for (int i = 0; i < HOST_MAX_DEVICES; i++) pthread_mutex_init(&g_arena[i].mu, NULL);
+    for (int i = 0; i < HOST_MAX_DEVICES; i++)
+        for (int k = 0; k < ARENA_SUBS; k++) pthread_mutex_init(&g_arena[i][k].mu, NULL);
 }
 static void* arena_reserve(arena_t* a, int which, size_t need) {
     dbuf_t* d = &a->buf[which];
@@ -297,6 +309,22 @@ static void* arena_reserve(arena_t* a, int which, size_t need) {
     }
     return d->p;
 }
+/* internal to the library (called by zxc_mi355x_release_cached in the shim): free every arena nobody holds */
+void zxc_host_release_arenas(void) {
+    pthread_once(&g_arena_once, arena_init_all);
+    const int cur = zxc_hip_current_device();
+    for (int dev = 0; dev < HOST_MAX_DEVICES; dev++)
+        for (int k = 0; k < ARENA_SUBS; k++) {
+            arena_t* a = &g_arena[dev][k];
+            if (pthread_mutex_trylock(&a->mu) != 0) continue; /* in use: its call trims it when it ends */
+            int any = 0;
+            for (int w = 0; w < AR_N; w++) any |= a->buf[w].p != NULL;
+            if (any && zxc_mi355x_set_device(dev) == ZXC_OK)
+                for (int w = 0; w < AR_N; w++) { zxc_mi355x_free(a->buf[w].p); a->buf[w].p = NULL; a->buf[w].cap = 0; }
+            pthread_mutex_unlock(&a->mu);
+        }
+    if (cur >= 0) (void)zxc_mi355x_set_device(cur);
+}
 
 /* Decode `n` jobs whose compressed bytes are h_comp[0..comp_bytes) on the host.
  * Output slot i is at jobs[i].out_off. Leaves statuses in h_status and, on success of the
@@ -308,6 +336,7 @@ typedef struct {
     void* d_status;
     void* d_dict; /* [dict content | 128-byte shared table] or NULL */
     arena_t* held;
+    void* stream; /* the stream the batch ran on (NULL: the device's default stream) */
 } dev_bufs_t;
 
 typedef struct {
@@ -319,20 +348,32 @@ typedef struct {
 static void dev_bufs_free(dev_bufs_t* b) {
     arena_t* a = b->held;
     memset(b, 0, sizeof(*b));
-    if (a) pthread_mutex_unlock(&a->mu);
+    if (a) {
+        for (int w = 0; w < AR_N; w++)
+            if (a->buf[w].cap > ARENA_KEEP_MAX) { zxc_mi355x_free(a->buf[w].p); a->buf[w].p = NULL; a->buf[w].cap = 0; }
+        pthread_mutex_unlock(&a->mu);
+    }
+}
+/* decoded bytes of the batch back to the host, on the batch's stream */
+static int dev_bufs_read(const dev_bufs_t* b, void* h_dst, size_t d_off, size_t bytes) {
+    if (bytes == 0) return ZXC_OK;
+    if (!b->stream) return zxc_mi355x_memcpy_d2h(h_dst, (const uint8_t*)b->d_out + d_off, bytes);
+    const int rc = zxc_hip_memcpy_d2h_async(h_dst, (const uint8_t*)b->d_out + d_off, bytes, b->stream);
+    return rc == ZXC_OK ? zxc_mi355x_synchronize(b->stream) : rc;
 }
 
-static int run_jobs_cap(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_job_t* jobs, uint32_t n,
-                        size_t out_bytes, uint32_t block_size, uint32_t cap_override, int verify_trailer,
-                        int32_t* h_status, dev_bufs_t* b, const dict_ref_t* dr) {
+static int run_jobs_on(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_job_t* jobs, uint32_t n,
+                       size_t out_bytes, uint32_t block_size, uint32_t cap_override, int verify_trailer,
+                       int32_t* h_status, dev_bufs_t* b, const dict_ref_t* dr, int sub, void* stream) {
     memset(b, 0, sizeof(*b));
     if (zxc_mi355x_device_count() <= 0) return ZXC_ERROR_GPU_UNAVAILABLE;
     const int dev = zxc_hip_current_device();
-    if (dev < 0 || dev >= HOST_MAX_DEVICES) return ZXC_ERROR_GPU_UNAVAILABLE;
+    if (dev < 0 || dev >= HOST_MAX_DEVICES || sub < 0 || sub >= ARENA_SUBS) return ZXC_ERROR_GPU_UNAVAILABLE;
     pthread_once(&g_arena_once, arena_init_all);
-    arena_t* a = &g_arena[dev];
+    arena_t* a = &g_arena[dev][sub];
     pthread_mutex_lock(&a->mu);
     b->held = a;
+    b->stream = stream;
     /* +64: the kernel's 16-byte literal / extras reads may run past the last block */
     b->d_comp = arena_reserve(a, AR_COMP, comp_bytes + 64);
     b->d_jobs = arena_reserve(a, AR_JOBS, (size_t)n * sizeof(zxc_dev_job_t));
@@ -340,11 +381,14 @@ static int run_jobs_cap(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_
     b->d_status = arena_reserve(a, AR_STATUS, (size_t)n * sizeof(int32_t));
     int rc = ZXC_ERROR_MEMORY;
     if (b->d_comp && b->d_jobs && b->d_out && b->d_status) {
-        rc = zxc_mi355x_memcpy_h2d(b->d_comp, h_comp, comp_bytes);
-        if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_h2d(b->d_jobs, jobs, (size_t)n * sizeof(zxc_dev_job_t));
+        rc = stream ? zxc_hip_memcpy_h2d_async(b->d_comp, h_comp, comp_bytes, stream) : zxc_mi355x_memcpy_h2d(b->d_comp, h_comp, comp_bytes);
+        if (rc == ZXC_OK)
+            rc = stream ? zxc_hip_memcpy_h2d_async(b->d_jobs, jobs, (size_t)n * sizeof(zxc_dev_job_t), stream)
+                        : zxc_mi355x_memcpy_h2d(b->d_jobs, jobs, (size_t)n * sizeof(zxc_dev_job_t));
         if (rc == ZXC_OK && dr && dr->dict_size) {
             b->d_dict = arena_reserve(a, AR_DICT, dr->dict_size + ZXC_HUF_TABLE_SIZE + 64);
             if (!b->d_dict) rc = ZXC_ERROR_MEMORY;
+            if (rc == ZXC_OK && stream) rc = zxc_mi355x_synchronize(stream); /* (the dictionary goes up with plain copies) */
             if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_h2d(b->d_dict, dr->dict, dr->dict_size);
             if (rc == ZXC_OK && dr->dict_huf)
                 rc = zxc_mi355x_memcpy_h2d((uint8_t*)b->d_dict + dr->dict_size, dr->dict_huf, ZXC_HUF_TABLE_SIZE);
@@ -353,12 +397,23 @@ static int run_jobs_cap(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_
             rc = zxc_hip_decode_blocks(b->d_comp, (const zxc_dev_job_t*)b->d_jobs, n, b->d_out, (int32_t*)b->d_status,
                                        block_size, verify_trailer, b->d_dict, b->d_dict ? (uint32_t)dr->dict_size : 0u,
                                        (b->d_dict && dr->dict_huf) ? (uint8_t*)b->d_dict + dr->dict_size : NULL,
-                                       cap_override, NULL);
-        if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(NULL);
-        if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(h_status, b->d_status, (size_t)n * sizeof(int32_t));
+                                       cap_override, stream);
+        if (rc == ZXC_OK && stream) {
+            rc = zxc_hip_memcpy_d2h_async(h_status, b->d_status, (size_t)n * sizeof(int32_t), stream);
+            if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(stream);
+        } else if (rc == ZXC_OK) {
+            rc = zxc_mi355x_synchronize(NULL);
+            if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(h_status, b->d_status, (size_t)n * sizeof(int32_t));
+        }
     }
     if (rc != ZXC_OK) dev_bufs_free(b);
     return rc;
+}
+
+static int run_jobs_cap(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_job_t* jobs, uint32_t n,
+                        size_t out_bytes, uint32_t block_size, uint32_t cap_override, int verify_trailer,
+                        int32_t* h_status, dev_bufs_t* b, const dict_ref_t* dr) {
+    return run_jobs_on(h_comp, comp_bytes, jobs, n, out_bytes, block_size, cap_override, verify_trailer, h_status, b, dr, 0, NULL);
 }
 
 static int run_jobs(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_job_t* jobs, uint32_t n,
@@ -464,6 +519,9 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
             if (rc != ZXC_OK) { ret = rc; break; }
             size_t op = total;
             for (uint32_t i = 0; i < n && rc == ZXC_OK; i++) {
+                /* the second run must reproduce the first one's verdicts: a status is never trusted as a copy length */
+                if (st[i] < 0) { rc = st[i]; break; }
+                if ((uint32_t)st[i] > slot || (size_t)st[i] > dst_capacity - op) { rc = ZXC_ERROR_CORRUPT_DATA; break; }
                 rc = zxc_mi355x_memcpy_d2h(dst + op, (const uint8_t*)b.d_out + (size_t)i * slot, (size_t)st[i]);
                 op += (size_t)st[i];
             }
@@ -827,69 +885,65 @@ int64_t zxc_mi355x_plan_seekable(const zxc_seekable* s, uint32_t first, uint32_t
     return (int64_t)n;
 }
 
-int64_t zxc_seekable_decompress_range(zxc_seekable* s, void* dst, const size_t dst_capacity, const uint64_t offset,
-                                      const size_t len) {
-    if (len == 0) return 0;
-    if (!s || !dst) return ZXC_ERROR_NULL_INPUT;
-    if (dst_capacity < len) return ZXC_ERROR_DST_TOO_SMALL;
-    if (offset > s->total_decomp || len > s->total_decomp - offset) return ZXC_ERROR_SRC_TOO_SMALL; /* (no wrap) */
-    if (s->dict_id != 0 && (!s->dict || s->dict_size == 0)) return ZXC_ERROR_DICT_REQUIRED;
+/* Bytes [offset, offset + len) of the archive into dst, on the calling thread's device, arena `sub`, stream `stream`:
+ * the covered blocks go to the device in batches of at most HOST_BATCH_BYTES of output slots (device memory is
+ * O(batch) whatever the range), each batch = one launch over its blocks' compressed span. */
+static int64_t seek_range_on(zxc_seekable* s, uint8_t* dst, const uint64_t offset, const size_t len, int sub, void* stream) {
     const dict_ref_t dr = {s->dict, s->dict_size, s->has_dict_huf ? s->dict_huf : NULL};
-
     const uint32_t b0 = (uint32_t)(offset / s->block_size);
     const uint32_t b1 = (uint32_t)((offset + len - 1) / s->block_size);
-    const uint32_t n = b1 - b0 + 1;
-    const uint64_t c0 = s->comp_offsets[b0], c1 = s->comp_offsets[b1 + 1];
-    if (c1 > s->src_size) return ZXC_ERROR_SRC_TOO_SMALL;
-    const size_t comp_bytes = (size_t)(c1 - c0);
-
-    /* compressed span of the covered blocks: borrowed buffer or reader callback */
-    const uint8_t* h_comp;
+    uint32_t batch_blocks = (uint32_t)(HOST_BATCH_BYTES / s->block_size);
+    if (batch_blocks < 16u) batch_blocks = 16u;
+    const uint32_t nmax = (b1 - b0 + 1u) < batch_blocks ? (b1 - b0 + 1u) : batch_blocks;
+    zxc_dev_job_t* jobs = (zxc_dev_job_t*)malloc((size_t)nmax * sizeof(*jobs));
+    int32_t* st = (int32_t*)malloc((size_t)nmax * sizeof(int32_t));
     uint8_t* staged = NULL;
-    if (s->src) {
-        h_comp = s->src + c0;
-    } else {
-        staged = (uint8_t*)malloc(comp_bytes ? comp_bytes : 1);
-        if (!staged) return ZXC_ERROR_MEMORY;
-        const int64_t r = s->reader.read_at(s->reader.ctx, staged, comp_bytes, c0);
-        if (r != (int64_t)comp_bytes) { free(staged); return r < 0 ? r : (int64_t)ZXC_ERROR_IO; }
-        h_comp = staged;
-    }
-    zxc_dev_job_t* jobs = (zxc_dev_job_t*)malloc((size_t)n * sizeof(*jobs));
-    int32_t* st = (int32_t*)malloc((size_t)n * sizeof(int32_t));
-    int64_t ret = ZXC_ERROR_MEMORY;
-    if (jobs && st) {
-        zxc_mi355x_plan_seekable(s, b0, n, c0, jobs);
+    size_t staged_cap = 0;
+    int64_t ret = (jobs && st) ? (int64_t)len : (int64_t)ZXC_ERROR_MEMORY;
+    for (uint32_t f = b0; ret >= 0 && f <= b1; f += nmax) {
+        const uint32_t n = (b1 - f + 1u) < nmax ? (b1 - f + 1u) : nmax;
+        const uint64_t c0 = s->comp_offsets[f], c1 = s->comp_offsets[f + n];
+        if (c1 > s->src_size) { ret = ZXC_ERROR_SRC_TOO_SMALL; break; }
+        const size_t comp_bytes = (size_t)(c1 - c0);
+        /* compressed span of the batch's blocks: borrowed buffer or reader callback */
+        const uint8_t* h_comp;
+        if (s->src) {
+            h_comp = s->src + c0;
+        } else {
+            if (staged_cap < comp_bytes) {
+                free(staged);
+                staged = (uint8_t*)malloc(comp_bytes ? comp_bytes : 1);
+                staged_cap = staged ? comp_bytes : 0;
+                if (!staged) { ret = ZXC_ERROR_MEMORY; break; }
+            }
+            const int64_t r = s->reader.read_at(s->reader.ctx, staged, comp_bytes, c0);
+            if (r != (int64_t)comp_bytes) { ret = r < 0 ? r : (int64_t)ZXC_ERROR_IO; break; }
+            h_comp = staged;
+        }
+        zxc_mi355x_plan_seekable(s, f, n, c0, jobs);
         /* The reference decodes each block with cap block_size + 2112 and keeps what
          * the range needs (zxc_seekable.c:758-780): keep whole slots here. */
         for (uint32_t k = 0; k < n; k++) jobs[k].out_len = s->block_size;
         dev_bufs_t b;
-        int rc = run_jobs(h_comp, comp_bytes, jobs, n, (size_t)n * s->block_size, s->block_size, 0, st, &b, &dr);
-        if (rc != ZXC_OK) {
-            ret = rc;
-        } else {
-            ret = (int64_t)len;
-            /* first failing block in job order wins (zxc_seekable.c:1097-1104) */
-            size_t remaining = len;
-            for (uint32_t k = 0; k < n; k++) {
-                if (st[k] < 0) { ret = st[k]; break; }
-                const uint64_t bstart = (uint64_t)(b0 + k) * s->block_size;
-                const size_t skip = offset > bstart ? (size_t)(offset - bstart) : 0;
-                const size_t want = (s->block_size - skip) < remaining ? (s->block_size - skip) : remaining;
-                /* a block that decodes short of what the range needs from it */
-                const size_t expect = zxc_seekable_get_block_decomp_size(s, b0 + k);
-                const size_t need = (expect - skip) < remaining ? (expect - skip) : remaining;
-                if ((size_t)st[k] < skip + need) { ret = ZXC_ERROR_CORRUPT_DATA; break; }
-                (void)want;
-                remaining -= need;
-            }
-            if (ret >= 0) {
-                const size_t skip0 = (size_t)(offset - (uint64_t)b0 * s->block_size);
-                rc = zxc_mi355x_memcpy_d2h(dst, (const uint8_t*)b.d_out + skip0, len);
-                if (rc != ZXC_OK) ret = rc;
-            }
-            dev_bufs_free(&b);
+        const int rc = run_jobs_on(h_comp, comp_bytes, jobs, n, (size_t)n * s->block_size, s->block_size, 0u, 0, st, &b, &dr, sub, stream);
+        if (rc != ZXC_OK) { ret = rc; break; }
+        /* first failing block in job order wins (zxc_seekable.c:1097-1104) */
+        const uint64_t lo = (uint64_t)f * s->block_size;                 /* decoded position of the batch's first byte */
+        const uint64_t from = offset > lo ? offset : lo;
+        const uint64_t batch_end = lo + (uint64_t)n * s->block_size;
+        const uint64_t to = (offset + len) < batch_end ? (offset + len) : batch_end;
+        for (uint32_t k = 0; k < n; k++) {
+            if (st[k] < 0) { ret = st[k]; break; }
+            /* a block that decodes short of what the range needs from it */
+            const uint64_t bstart = lo + (uint64_t)k * s->block_size;
+            const uint64_t bneed_hi = to < bstart + zxc_seekable_get_block_decomp_size(s, f + k) ? to : bstart + zxc_seekable_get_block_decomp_size(s, f + k);
+            if (bneed_hi > bstart && (uint64_t)st[k] < bneed_hi - bstart) { ret = ZXC_ERROR_CORRUPT_DATA; break; }
         }
+        if (ret >= 0 && to > from) {
+            const int crc = dev_bufs_read(&b, dst + (size_t)(from - offset), (size_t)(from - lo), (size_t)(to - from));
+            if (crc != ZXC_OK) ret = crc;
+        }
+        dev_bufs_free(&b);
     }
     free(jobs);
     free(st);
@@ -897,10 +951,108 @@ int64_t zxc_seekable_decompress_range(zxc_seekable* s, void* dst, const size_t d
     return ret;
 }
 
+static int64_t seek_range_check(zxc_seekable* s, void* dst, const size_t dst_capacity, const uint64_t offset, const size_t len) {
+    if (!s || !dst) return ZXC_ERROR_NULL_INPUT;
+    if (dst_capacity < len) return ZXC_ERROR_DST_TOO_SMALL;
+    if (offset > s->total_decomp || len > s->total_decomp - offset) return ZXC_ERROR_SRC_TOO_SMALL; /* (no wrap) */
+    if (s->dict_id != 0 && (!s->dict || s->dict_size == 0)) return ZXC_ERROR_DICT_REQUIRED;
+    return 0;
+}
+
+int64_t zxc_seekable_decompress_range(zxc_seekable* s, void* dst, const size_t dst_capacity, const uint64_t offset,
+                                      const size_t len) {
+    if (len == 0) return 0;
+    const int64_t chk = seek_range_check(s, dst, dst_capacity, offset, len);
+    if (chk < 0) return chk;
+    return seek_range_on(s, (uint8_t*)dst, offset, len, 0, NULL);
+}
+
+/* The multi-threaded range decode (reference: zxc_seekable.c:1033-1108 plans one job per block and lets n_threads workers
+ * pull them). Here a block is a workgroup's work, so host threads add nothing on ONE device; what they are for is
+ * SEVERAL devices: the covered blocks are cut into min(n_threads, devices) contiguous parts, one host thread + stream +
+ * staging arena per part, each on its own device; n_threads == 0 takes every device. The devices are those of
+ * ZXC_MI355X_DEVICES (a comma-separated list of ordinals; an ordinal may repeat: two workers, two streams on that
+ * device) or, without it, all of them. First failing part in block order wins, like the reference's job scan. */
+typedef struct {
+    zxc_seekable* s;
+    uint8_t* dst;
+    uint64_t offset;
+    size_t len;
+    int device, sub;
+    int64_t result;
+} seek_part_t;
+static void* seek_part_main(void* p) {
+    seek_part_t* a = (seek_part_t*)p;
+    void* stream = NULL;
+    if (zxc_mi355x_set_device(a->device) != ZXC_OK || zxc_hip_stream_create(&stream) != ZXC_OK) {
+        a->result = ZXC_ERROR_GPU_UNAVAILABLE;
+        return NULL;
+    }
+    a->result = seek_range_on(a->s, a->dst, a->offset, a->len, a->sub, stream);
+    zxc_hip_stream_destroy(stream);
+    return NULL;
+}
+static int device_list(int* devs, int cap) {
+    const int count = zxc_mi355x_device_count();
+    int n = 0;
+    const char* e = getenv("ZXC_MI355X_DEVICES");
+    if (e && *e) {
+        while (*e && n < cap) {
+            char* end = NULL;
+            const long v = strtol(e, &end, 10);
+            if (end == e) break;
+            if (v >= 0 && v < count) devs[n++] = (int)v;
+            e = (*end == ',') ? end + 1 : end;
+            if (*end != ',' && *end != 0) break;
+        }
+    } else {
+        for (int i = 0; i < count && n < cap; i++) devs[n++] = i;
+    }
+    return n;
+}
+
 int64_t zxc_seekable_decompress_range_mt(zxc_seekable* s, void* dst, const size_t dst_capacity, const uint64_t offset,
                                          const size_t len, int n_threads) {
-    (void)n_threads; /* block-level parallelism is the GPU launch's; CPU threads add nothing */
-    return zxc_seekable_decompress_range(s, dst, dst_capacity, offset, len);
+    if (len == 0) return 0;
+    const int64_t chk = seek_range_check(s, dst, dst_capacity, offset, len);
+    if (chk < 0) return chk;
+    int devs[HOST_MAX_DEVICES * ARENA_SUBS];
+    int nd = device_list(devs, (int)(sizeof devs / sizeof devs[0]));
+    const uint32_t b0 = (uint32_t)(offset / s->block_size);
+    const uint32_t b1 = (uint32_t)((offset + len - 1) / s->block_size);
+    const uint32_t nblocks = b1 - b0 + 1u;
+    int parts = n_threads == 0 ? nd : (n_threads < nd ? n_threads : nd);
+    if ((uint32_t)parts > nblocks) parts = (int)nblocks;
+    if (parts <= 1) return zxc_seekable_decompress_range(s, dst, dst_capacity, offset, len);
+    seek_part_t part[HOST_MAX_DEVICES * ARENA_SUBS];
+    pthread_t th[HOST_MAX_DEVICES * ARENA_SUBS];
+    int live[HOST_MAX_DEVICES * ARENA_SUBS];
+    int used[HOST_MAX_DEVICES];
+    memset(used, 0, sizeof used);
+    for (int k = 0; k < parts; k++) {
+        /* blocks [b0 + k*N/P, b0 + (k+1)*N/P): zxc_mi355x block_range's cut, in bytes of the range */
+        const uint32_t f = b0 + (uint32_t)(((uint64_t)nblocks * (uint32_t)k) / (uint32_t)parts);
+        const uint32_t l = b0 + (uint32_t)(((uint64_t)nblocks * (uint32_t)(k + 1)) / (uint32_t)parts);
+        const uint64_t lo = (uint64_t)f * s->block_size, hi = (uint64_t)l * s->block_size;
+        const uint64_t from = offset > lo ? offset : lo, to = (offset + len) < hi ? (offset + len) : hi;
+        part[k].s = s;
+        part[k].dst = (uint8_t*)dst + (size_t)(from - offset);
+        part[k].offset = from;
+        part[k].len = (size_t)(to - from);
+        part[k].device = devs[k];
+        part[k].sub = used[devs[k]]++ % ARENA_SUBS;
+        part[k].result = ZXC_ERROR_GPU_UNAVAILABLE;
+        live[k] = 0;
+        if (part[k].len == 0) { part[k].result = 0; continue; }
+        if (pthread_create(&th[k], NULL, seek_part_main, &part[k]) != 0) part[k].result = ZXC_ERROR_MEMORY;
+        else live[k] = 1;
+    }
+    int64_t ret = (int64_t)len;
+    for (int k = 0; k < parts; k++)
+        if (live[k]) pthread_join(th[k], NULL);
+    for (int k = 0; k < parts; k++)
+        if (part[k].result < 0) { ret = part[k].result; break; }
+    return ret;
 }
 
 
@@ -935,6 +1087,17 @@ static size_t block_size_ceil(size_t v) { /* zxc_block_size_ceil, src/lib/zxc_in
     size_t bs = ZXC_BLOCK_SIZE_MIN;
     while (bs < v) bs <<= 1;
     return bs;
+}
+
+/* reference include/zxc_buffer.h:382: estimated peak working memory of one zxc_compress_block call of src_size bytes. Here
+ * the working memory is DEVICE memory of the staging arena: the source block, its output slot (2 x block + 512) and, at
+ * levels 6-7, the four PivCo level buffers; 0 for src_size 0, sizes round up to the block-size tiers. */
+uint64_t zxc_estimate_cctx_size(const size_t src_size, const int level) {
+    if (src_size == 0) return 0;
+    const uint64_t bs = block_size_ceil(src_size < ZXC_BLOCK_SIZE_MIN ? ZXC_BLOCK_SIZE_MIN : src_size);
+    uint64_t est = sizeof(struct zxc_cctx_s) + bs + 64u + (2u * bs + 512u) + 4096u;
+    if (level >= 6) est += 4u * (bs + 64u);
+    return est;
 }
 
 zxc_cctx* zxc_create_cctx(const zxc_compress_opts_t* opts) {
