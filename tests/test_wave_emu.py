@@ -212,3 +212,18 @@ def test_encoder_pivco_sections_on_emulator(emu, ref, oracle):
             if name == "one_token" and level == 7:
                 assert any(et == 2 for t, el, et in fields), fields
     assert seen_lit >= 6 and seen_tok >= 3
+
+
+def test_overflow_margin_frames_on_emulator(emu, oracle):
+    """The constructed frames of tests/golden/craft.py (the reference's OVERFLOW-by-batch-reserve cases): the kernels give the
+    block the oracle's verdict — decoded to 6140 bytes, or BAD_OFFSET."""
+    import craft
+    import emu_py
+    for name, (f, want) in craft.overflow_margin_frames(oracle).items():
+        jobs, bs, ck, total = emu_py.frame_jobs(f)
+        jobs["out_len"] = 6208  # (the host API decodes an irregular frame with one capacity-sized slot per block)
+        st, out = emu.decode_jobs(f, jobs, 6208, bs)
+        rc, dec = oracle.decode_block(f[16:16 + int(jobs["comp_size"][0])], bs, cap=6208)
+        assert st[0] == rc, (name, st[0], rc)
+        if rc > 0:
+            assert out[:rc] == dec[:rc]

@@ -966,6 +966,14 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
     return (int)p;
 }
 
+// The sequence executor of round 3 (8-waves-per-SIMD capable, far sources requested early, aligned loads, whole-KiB
+// flushes). Both kernels run it: the lean kernel on raw sections, the full kernel on the sections it has expanded into its
+// scratch slot; run_sequences() above remains for archives with a dictionary.
+#ifndef LEAN_WAVES_PER_SIMD
+#define LEAN_WAVES_PER_SIMD 6
+#endif
+#include "zxc_seq_lean.inc"
+
 // Scratch (expanded literals / PivCo ping-pong / decoded tokens) is only needed by blocks with
 // an RLE or PivCo section. Slots come from a small pool sized to the number of workgroups that
 // can be resident at once, so a free one always exists: lane 0 claims one with atomicCAS.
@@ -1108,6 +1116,7 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
         S.off8 = 0;
         S.ext = S.tok + 4ull * S.n_seq;
         S.ext_size = avail - (uint32_t)consumed;
+        if (!DICT) return run_sequences_lean<true>(S, dst, out_len, cap, reinterpret_cast<LeanLds&>(L), lane);
         return run_sequences<DICT, true>(S, dst, out_len, cap, L, lane);
     }
     const uint32_t desc = (enc_lit != 0u ? 4u : 0u) + (enc_tok == 2u ? 4u : 0u);
@@ -1176,6 +1185,7 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
 #ifdef ZXC_EXPERIMENT
     if (dbg & DBG_NO_SEQ) return (int)out_len;
 #endif
+    if (!DICT) return run_sequences_lean<false>(S, dst, out_len, cap, reinterpret_cast<LeanLds&>(L), lane);
     return run_sequences<DICT, false>(S, dst, out_len, cap, L, lane);
 }
 
@@ -1312,11 +1322,6 @@ __device__ __forceinline__ bool block_needs_full_kernel(const uint8_t* __restric
 // One wavefront per block like the full kernel, built for LEAN_WAVES_PER_SIMD waves per SIMD (<= 64 VGPRs, < 5 KiB LDS):
 // RAW blocks and GLO / GHI blocks with raw sections, no checksum, no dictionary. A block it cannot take is appended to
 // `list` for the full kernel (see above) and its status slot is left alone.
-#ifndef LEAN_WAVES_PER_SIMD
-#define LEAN_WAVES_PER_SIMD 6
-#endif
-#include "zxc_seq_lean.inc"
-
 extern "C" __global__ void __launch_bounds__(64, LEAN_WAVES_PER_SIMD)
 zxc_decode_blocks_lean_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
                               uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,

@@ -47,6 +47,7 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 // every candidate is verified against the bytes. Half the LDS of 32-bit entries -> twice the waves.
 
 __device__ __forceinline__ uint32_t e_ld8(const uint8_t* p) { return *p; }
+__device__ __forceinline__ uint32_t e_ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ uint64_t e_ld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ __forceinline__ v4u e_ld128(const uint8_t* p) { v4u v; __builtin_memcpy(&v, p, 16); return v; }
 __device__ __forceinline__ uint32_t e_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -219,8 +220,10 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         const uint32_t i = c0 + (uint32_t)lane;
         const bool can = i < limit && i >= D;
         uint64_t v = 0, vh = 0;
+        v4u v_cur;
         if (c_next != c0 && can) v_next = e_ld128(in + i);  // (a long match skipped ahead: the prefetch was for another chunk)
         {   // request the following chunk's bytes now; they arrive while this chunk is matched, parsed and emitted
+            v_cur = v_next;
             v = (uint64_t)v_next.x | ((uint64_t)v_next.y << 32);
             vh = (uint64_t)v_next.z | ((uint64_t)v_next.w << 32);
             c_next = c0 + 64u;
@@ -236,6 +239,10 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         }
         // ---- 2. chain walk, NC candidates per round (zxc_lz77_find_best_match :262-440)
         uint32_t len = 0, dist = 0, tried = 0, d = d0;
+        // my own second 16 bytes: the same for every round of the walk (may reach up to 16 bytes past the block: lengths are
+        // clamped to it below)
+        const v4u own1 = v_cur;
+        const v4u own2 = e_ld128((can ? in + i : in) + 16u);
         for (;;) {
             const bool act = d != 0u && tried < depth && len < sufficient;
             if (__ballot(act) == 0ull) break;
@@ -256,20 +263,46 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             uint32_t dk[NC + 1];
             v4u c1[NC], c2[NC];
             dk[0] = act ? d : 0u;
-            const v4u own2 = e_ld128(pme + 16u);  // (may reach up to 16 bytes past the block: lengths are clamped to it below)
+#ifdef ENC_PREFILTER  // experiment (profiles/r3l_encab.log: -6 % at level 3, -10 % at level 5): the 4-byte look costs a second, dependent
+                      // memory round trip per round, and with 6 workgroups per CU the walk is bound by round trips, not by the address pipeline
+            // Round 3: a 4-byte look at every candidate first (the reference's prefilter, src/lib/zxc_compress.c:300-330).
+            // An unaligned 16-byte gather costs the CU's address pipeline 4 clocks per active lane, an unaligned dword
+            // 1.3 (profiles/r3_vmem_test.log), and most candidates of a 13-bit bucket differ within their first four bytes:
+            // the 32 bytes of a candidate are only requested by the lanes whose candidate passed.
+            uint32_t cw[NC];
+#pragma unroll
+            for (uint32_t k = 0; k < NC; k++) {
+                cw[k] = e_ld32(pme - dk[k]);
+                dk[k + 1] = next(dk[k], tried + k + 1u < depth);
+            }
+            bool pass[NC];
+#pragma unroll
+            for (uint32_t k = 0; k < NC; k++) {
+                pass[k] = dk[k] != 0u && cw[k] == (uint32_t)v;
+                c1[k] = own1;   // (a candidate that failed compares as "0 bytes equal" below: mk is forced to 0)
+                c2[k] = own2;
+                if (pass[k]) {
+                    c1[k] = e_ld128(pme - dk[k]);
+                    c2[k] = e_ld128(pme - dk[k] + 16u);
+                }
+            }
+#else
+            bool pass[NC];
 #pragma unroll
             for (uint32_t k = 0; k < NC; k++) {
                 c1[k] = e_ld128(pme - dk[k]);
                 c2[k] = e_ld128(pme - dk[k] + 16u);
                 dk[k + 1] = next(dk[k], tried + k + 1u < depth);
+                pass[k] = dk[k] != 0u;
             }
+#endif
             const uint64_t o2lo = (uint64_t)own2.x | ((uint64_t)own2.y << 32), o2hi = (uint64_t)own2.z | ((uint64_t)own2.w << 32);
             uint32_t mk[NC];
             bool lk[NC];
             bool anylive = false;
 #pragma unroll
             for (uint32_t k = 0; k < NC; k++) {
-                mk[k] = dk[k] ? prefix16(v, vh, c1[k]) : 0u;
+                mk[k] = pass[k] ? prefix16(v, vh, c1[k]) : 0u;
                 if (mk[k] == 16u) mk[k] += prefix16(o2lo, o2hi, c2[k]);
                 lk[k] = mk[k] == 32u;
                 anylive |= lk[k];
