@@ -47,11 +47,11 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
     } else {
         // the two-pass launch of zxc_hip_shim.hip: the lean kernel over every block (in a launch order that is not the
         // identity), then the full kernel, a fixed grid walking the list of blocks the lean kernel handed over
-        std::vector<uint32_t> order(n_jobs), list(n_jobs + 1u, 0u);
+        std::vector<uint32_t> order(n_jobs), list(n_jobs + 2u, 0u);
         for (uint32_t b = 0; b < n_jobs; b++) {
             order[b] = n_jobs - 1u - b;
             // (what zxc_order_scatter_kernel appends, by the same predicate)
-            if (block_needs_full_kernel(c.data() + 4096 + jobs[order[b]].comp_off, jobs[order[b]].comp_size)) list[1u + list[0]++] = b;
+            if (block_needs_full_kernel(c.data() + 4096 + jobs[order[b]].comp_off, jobs[order[b]].comp_size)) list[2u + list[0]++] = b;
         }
         for (uint32_t b = 0; b < n_jobs; b++) {
             memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));

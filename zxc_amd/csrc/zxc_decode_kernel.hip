@@ -1287,12 +1287,23 @@ zxc_decode_blocks_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* 
                          uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,
                          uint32_t trailer_bytes, uint8_t* __restrict__ scratch, uint32_t scratch_stride, uint32_t dbg,
                          uint32_t* __restrict__ slot_busy, uint32_t n_slots, const uint32_t* __restrict__ order,
-                         uint32_t cap_override, const uint32_t* __restrict__ list) {
-    // (one call site for both modes: a plain launch has one block per workgroup, grid = n_jobs)
-    const uint32_t n = list ? uni(__hip_atomic_load(list, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : n_jobs;
-    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+                         uint32_t cap_override, uint32_t* __restrict__ list) {
+    // (one call site for both modes. Plain launch: one block per workgroup, grid = n_jobs, the hardware dispatcher is the
+    // dynamic scheduler. List mode: a fixed grid of workgroups PULLS list entries through a counter — list[0] = number of
+    // entries, list[1] = next entry to hand out, entries from list[2] — so a slow block delays only its own workgroup.)
+    if (!list) {
         decode_one_block<false>(comp, jobs, n_jobs, out, status, block_size, trailer_bytes, scratch, scratch_stride, dbg,
-                                slot_busy, n_slots, order, cap_override, nullptr, 0u, nullptr, list ? uni(list[1u + i]) : i);
+                                slot_busy, n_slots, order, cap_override, nullptr, 0u, nullptr, blockIdx.x);
+        return;
+    }
+    const uint32_t n = uni(__hip_atomic_load(list, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    for (;;) {
+        uint32_t i = 0;
+        if (threadIdx.x == 0) i = atomicAdd(list + 1, 1u);
+        i = uni(i);
+        if (i >= n) break;
+        decode_one_block<false>(comp, jobs, n_jobs, out, status, block_size, trailer_bytes, scratch, scratch_stride, dbg,
+                                slot_busy, n_slots, order, cap_override, nullptr, 0u, nullptr, uni(list[2u + i]));
         wave_lds_fence();
     }
 }
@@ -1428,7 +1439,7 @@ zxc_order_scatter_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* 
     __syncthreads();
     if (i < n_jobs) {
         order[base[bk] + rank] = i;
-        // two-pass launches: positions (in launch order) of the blocks the full kernel decodes; list[0] = their number
-        if (list && block_needs_full_kernel(comp + jobs[i].comp_off, jobs[i].comp_size)) list[1u + atomicAdd(list, 1u)] = base[bk] + rank;
+        // two-pass launches: positions (in launch order) of the blocks the full kernel decodes; list[0] = their number, list[1] = 0
+        if (list && block_needs_full_kernel(comp + jobs[i].comp_off, jobs[i].comp_size)) list[2u + atomicAdd(list, 1u)] = base[bk] + rank;
     }
 }

@@ -13,7 +13,7 @@ extern "C" __global__ void zxc_decode_blocks_kernel(const uint8_t* comp, const z
                                                     uint8_t* out, int32_t* status, uint32_t block_size,
                                                     uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride, uint32_t dbg,
                                                     uint32_t* slot_busy, uint32_t n_slots, const uint32_t* order,
-                                                    uint32_t cap_override, const uint32_t* list);
+                                                    uint32_t cap_override, uint32_t* list);
 extern "C" __global__ void zxc_decode_blocks_lean_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                          uint8_t* out, int32_t* status, uint32_t block_size,
                                                          const uint32_t* order, uint32_t cap_override);
@@ -224,7 +224,7 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
     // over every block, and the full kernel over the list of blocks with a coded section, which the launch-order pass builds
     // from the block headers. The two run side by side: the full kernel on a helper stream forked from the caller's and joined
     // back into it (event fork / join: capturable, no host synchronisation). Per-stream buffer:
-    // [128 u32 histogram + cursors | list[n + 1] | order[n]]; heaviest-first dispatch order (a launch ends when its slowest
+    // [128 u32 histogram + cursors | list: count, next, n entries | order[n]]; heaviest-first dispatch order (a launch ends when its slowest
     // block ends).
     const bool two_pass = !d_dict && !d_dict_huf && !verify_trailer && !(g_debug_flags & 0x40000000u);
     const bool want_order = two_pass || (n_jobs > max_slots && !(g_debug_flags & 0x80000000u));
@@ -238,7 +238,7 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
             if (!g_dev[dev].ord[i].used) { k = i; g_dev[dev].ord[i].used = 1; g_dev[dev].ord[i].stream = stream; }
         if (k >= 0) {  // (more distinct streams than buffers: one kernel in plain order, still correct)
             auto& o = g_dev[dev].ord[k];
-            const size_t want = 128u + 2u * (size_t)n_jobs + 1u;
+            const size_t want = 130u + 2u * (size_t)n_jobs;
             if (o.cap < want) {
                 if (o.buf) (void)hipFree(o.buf);
                 o.buf = NULL;
@@ -254,14 +254,14 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
                 }
             }
             uint32_t* buf = o.buf;
-            if (buf && hipMemsetAsync(buf, 0, 129u * 4u, (hipStream_t)stream) == hipSuccess) {
+            if (buf && hipMemsetAsync(buf, 0, 130u * 4u, (hipStream_t)stream) == hipSuccess) {
                 if (two_pass && o.aux) list = buf + 128;
                 const uint32_t g = (n_jobs + 255u) / 256u;
                 hipLaunchKernelGGL(zxc_order_hist_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
                                    d_jobs, n_jobs, block_size, buf);
                 hipLaunchKernelGGL(zxc_order_scatter_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream,
-                                   (const uint8_t*)d_comp, d_jobs, n_jobs, block_size, buf, buf + 129 + n_jobs, list);
-                order = buf + 129 + n_jobs;
+                                   (const uint8_t*)d_comp, d_jobs, n_jobs, block_size, buf, buf + 130 + n_jobs, list);
+                order = buf + 130 + n_jobs;
             }
         }
     }
@@ -287,7 +287,7 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
     } else
         hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
                            d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, verify_trailer ? 4u : 0u,
-                           pool.scratch, stride, g_debug_flags, pool.busy, n_slots, order, cap_override, (const uint32_t*)NULL);
+                           pool.scratch, stride, g_debug_flags, pool.busy, n_slots, order, cap_override, (uint32_t*)NULL);
     return hipGetLastError() == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
 }
 
