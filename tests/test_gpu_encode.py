@@ -95,19 +95,27 @@ def test_seekable_archive_structure(gpu, ref):
     assert rc == 200000 and out == data[65536 * 3 + 17: 65536 * 3 + 17 + 200000]
 
 
-def test_large_corpus_and_ratio(gpu, ref):
-    """Ratio within 3 % of the reference encoder at the same level (levels 3 and 5), on the silesia-like mix and
-    on enwik-like text; every archive round-trips through the unmodified reference decoder."""
+# Archive size against the reference encoder's at the same level. Levels 3 and 5 search like the reference does (same hash,
+# chain walk, lazy probes): within 3 %. Levels 1, 2 and 4 differ by design (every position is inserted, no skip
+# acceleration), levels 6-7 parse lazily where the reference runs its optimal-parse DP (src/lib/zxc_compress.c:795-1042) and
+# code their sections with the same PivCo format: within 5 % (every level is asserted, on both corpora).
+RATIO_BOUND = {1: 1.05, 2: 1.05, 3: 1.03, 4: 1.05, 5: 1.03, 6: 1.05, 7: 1.05}
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4, 5, 6, 7])
+def test_large_corpus_and_ratio(gpu, ref, level):
+    """Size within RATIO_BOUND of the reference encoder at the same level, on the silesia-like mix and on enwik-like text;
+    every archive round-trips through the unmodified reference decoder."""
     from zxc_amd import corpus
-    for what, data in (("synth_silesia", corpus.synth_silesia(32 << 20, seed=0)), ("synth_text", corpus.synth_text(32 << 20, seed=1))):
-        for level in (3, 5):
-            comp = gpu.compress(data, level, 65536, True)
-            rc, out = ref.decompress(comp, len(data))
-            assert rc == len(data) and hashlib.sha256(out).digest() == hashlib.sha256(data).digest()
-            cpu = ref.compress(data, level, 65536, True, False)
-            print(f"\n{what} level {level}: GPU encoder {len(comp)} B vs reference {len(cpu)} B "
-                  f"(ratio {len(data)/len(comp):.3f} vs {len(data)/len(cpu):.3f})")
-            assert len(comp) <= 1.03 * len(cpu), (what, level, len(comp), len(cpu))
+    mib = 32 if level <= 5 else 16   # (the reference's level 6-7 encoder runs at ~8 MB/s per thread)
+    for what, data in (("synth_silesia", corpus.synth_silesia(mib << 20, seed=0)), ("synth_text", corpus.synth_text(mib << 20, seed=1))):
+        comp = gpu.compress(data, level, 65536, True)
+        rc, out = ref.decompress(comp, len(data))
+        assert rc == len(data) and hashlib.sha256(out).digest() == hashlib.sha256(data).digest()
+        cpu = ref.compress(data, level, 65536, True, False)
+        print(f"\n{what} level {level}: GPU encoder {len(comp)} B vs reference {len(cpu)} B "
+              f"(ratio {len(data)/len(comp):.3f} vs {len(data)/len(cpu):.3f}, size x{len(comp)/len(cpu):.4f})")
+        assert len(comp) <= RATIO_BOUND[level] * len(cpu), (what, level, len(comp), len(cpu))
 
 
 def test_dictionary_compression(gpu, oracle, ref):
