@@ -1,13 +1,21 @@
 #!/bin/bash
-# tools/profile.sh <tag> : rocprofv3 passes of the default bench command (kernel trace + stats, then the HBM
-# traffic counters each in its own --pmc run) -> gpurun_out/<tag>_{kt,fetch,write}/ ; condense with
-# python tools/profile_summary.py <tag>
+# tools/profile.sh <tag> [bench args...] : rocprofv3 passes of a bench command (kernel trace + stats, then the HBM traffic
+# counters and the instruction counts, each in its own --pmc run) -> gpurun_out/<tag>_{kt,fetch,write,sq}/ ; condense with
+# python tools/profile_summary.py <tag> [what]
+# Default command: the headline decode (python bench.py --no-secondary --calib). Examples:
+#   tools/profile.sh r3              headline (configs[1])
+#   tools/profile.sh r3l7 --level 7 --tiles 10          level-7 decode (configs[4])
+#   tools/profile.sh r3enc --mode encode --enc-mib 1024 encoder (configs[2])
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-tag=$1
-CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --calib $PROFILE_BENCH_ARGS"
-timeout -k 5 ${PROFILE_TIMEOUT:-300} rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_kt -o kt --output-format csv -- $CMD > $R/gpurun_out/${tag}_kt.log 2>&1
-timeout -k 5 ${PROFILE_TIMEOUT:-300} rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${tag}_fetch -o f --output-format csv -- $CMD > $R/gpurun_out/${tag}_fetch.log 2>&1
-timeout -k 5 ${PROFILE_TIMEOUT:-300} rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${tag}_write -o w --output-format csv -- $CMD > $R/gpurun_out/${tag}_write.log 2>&1
-timeout -k 5 ${PROFILE_TIMEOUT:-300} rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES -d $R/gpurun_out/${tag}_sq -o s --output-format csv -- $CMD > $R/gpurun_out/${tag}_sq.log 2>&1
-ls $R/gpurun_out/${tag}_*/
+tag=$1; shift
+extra="$*"
+case "$extra" in *--mode\ encode*) base="--steps 5 --warmup 1 --no-cpu-baseline";; *) base="--steps 5 --warmup 2 --no-cpu-baseline --no-secondary --calib";; esac
+CMD="python $R/bench.py $base $extra"
+T=${PROFILE_TIMEOUT:-400}
+timeout -k 5 $T rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_kt -o kt --output-format csv -- $CMD > $R/gpurun_out/${tag}_kt.log 2>&1
+timeout -k 5 $T rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${tag}_fetch -o f --output-format csv -- $CMD > $R/gpurun_out/${tag}_fetch.log 2>&1
+timeout -k 5 $T rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${tag}_write -o w --output-format csv -- $CMD > $R/gpurun_out/${tag}_write.log 2>&1
+timeout -k 5 $T rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES -d $R/gpurun_out/${tag}_sq -o s --output-format csv -- $CMD > $R/gpurun_out/${tag}_sq.log 2>&1
+timeout -k 5 $T rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum -d $R/gpurun_out/${tag}_tcp -o t --output-format csv -- $CMD > $R/gpurun_out/${tag}_tcp.log 2>&1
+ls $R/gpurun_out/${tag}_*/ | head -30

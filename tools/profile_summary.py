@@ -1,78 +1,124 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 CSV outputs (gpurun_out/<tag>_{kt,fetch,write,sq}) into profiles/<tag>_*.
-Usage: python tools/profile_summary.py r1"""
+"""Condense the rocprofv3 CSV outputs of tools/profile.sh (gpurun_out/<tag>_{kt,fetch,write,sq,tcp}) into
+profiles/<tag>_summary.json + <tag>_kernel_stats.csv, and enter the launch's HBM traffic into profiles/r3_traffic.json
+(the table bench.py's roofline.traffic is read from).
+
+usage: profile_summary.py <tag> [decode|encode]
+
+Round 3: a decode launch is TWO kernels side by side (zxc_decode_blocks_lean_kernel over every block, zxc_decode_blocks_kernel
+over the list of blocks with coded sections, zxc_hip_shim.hip): counters are summed over both per launch, the launch time is
+the pair's span in the kernel trace. FETCH_SIZE is corrected per access pattern (profiles/r3_gather_calibration.log): the
+calibration launch of the run (RAW blocks = a 16 B/lane stream of known size) gives the STREAM factor (x1.98: 128-byte
+requests tallied at 64 B); the decode kernels' own reads are single-sector gathers and short runs, for which the counter
+reads x1.0 .. x1.2 of the truth: the raw counter x1.107 (the 16-byte gather figure) is reported, with the bracket."""
 import collections, csv, json, os, shutil, sys
 tag = sys.argv[1]
-KERNEL_ARG = sys.argv[2] if len(sys.argv) > 2 else None  # e.g. zxc_encode_blocks_kernel_l34 for the encode bench
+what = sys.argv[2] if len(sys.argv) > 2 else "decode"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out"); P = os.path.join(ROOT, "profiles"); os.makedirs(P, exist_ok=True)
-KERNEL = KERNEL_ARG or "zxc_decode_blocks_kernel"
+DEC = ("zxc_decode_blocks_lean_kernel", "zxc_decode_blocks_kernel")
+GATHER_FACTOR, GATHER_BRACKET = 1.107, (1.0, 1.2)
 
-CALIB = {}  # counter -> value of the calibration launch (bench.py --calib: the first decode-kernel dispatch)
+
+def is_ours(name):
+    if what == "encode":
+        return name.startswith("zxc_encode_blocks_kernel")
+    return any(name.split("(")[0].strip() == k for k in DEC)
 
 
-def counters(path):
-    per = collections.defaultdict(lambda: collections.defaultdict(float))
+def counters(path, skip_first):
+    """-> {counter: mean per launch}, launches. Per kernel the dispatches are taken in order; the first one of each decode
+    kernel is the calibration launch (bench.py --calib) and is returned separately."""
+    per = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
     for r in csv.DictReader(open(path)):
-        if KERNEL in r["Kernel_Name"]:
-            per[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
-    if KERNEL_ARG is None:
-        for c, d in per.items():  # bench.py --calib: first launch = RAW-only archive of known size, not a workload launch
-            first = min(d)
-            CALIB[c] = d.pop(first)
-    return {c: sum(d.values()) / len(d) for c, d in per.items()}, {c: len(d) for c, d in per.items()}
+        k = r["Kernel_Name"].split("(")[0].strip()
+        if is_ours(k):
+            per[r["Counter_Name"]][k][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+    mean, calib, n = {}, {}, 0
+    for c, bykern in per.items():
+        tot = 0.0
+        for k, d in bykern.items():
+            ids = sorted(d)
+            if skip_first and ids:
+                calib[c] = calib.get(c, 0.0) + d[ids[0]]
+                ids = ids[1:]
+            if ids:
+                tot += sum(d[i] for i in ids) / len(ids)
+                n = max(n, len(ids))
+        mean[c] = tot
+    return mean, calib, n
 
-out = {"kernel": KERNEL, "tag": tag}
+
+out = {"tag": tag, "what": what, "kernels": list(DEC) if what == "decode" else "zxc_encode_blocks_kernel_*"}
 ks = os.path.join(G, f"{tag}_kt", "kt_kernel_stats.csv")
-shutil.copyfile(ks, os.path.join(P, f"{tag}_kernel_stats.csv"))
-for r in csv.DictReader(open(ks)):
-    if KERNEL in r["Name"]:
-        out["kernel_trace"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
-                               "max_ns": float(r["MaxNs"]), "pct_of_gpu_time": float(r["Percentage"])}
-# steady state only: bench.py --calib --warmup 2 --steps 5 launches [calibration, 2 warm-up, 5 timed, 1 re-check]
+if os.path.exists(ks):
+    shutil.copyfile(ks, os.path.join(P, f"{tag}_kernel_stats.csv"))
+    out["kernel_stats"] = [{"name": r["Name"][:60], "calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 1),
+                            "pct": float(r["Percentage"])} for r in csv.DictReader(open(ks)) if is_ours(r["Name"].split("(")[0].strip())]
 kt = os.path.join(G, f"{tag}_kt", "kt_kernel_trace.csv")
+calib_launch = what == "decode"
 if os.path.exists(kt):
-    d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-               for r in csv.DictReader(open(kt)) if KERNEL in r["Kernel_Name"])
-    timed = [x[1] for x in (d[3:8] if KERNEL_ARG is None else d[1:6])]  # encode bench: 1 warm-up, 5 timed
-    if timed:
-        out["kernel_trace"]["steady_state_avg_ns"] = sum(timed) / len(timed)
-        out["kernel_trace"]["steady_state_launches"] = len(timed)
-        if KERNEL_ARG is None:
-            out["kernel_trace"]["calibration_launch_ns"] = d[0][1]
+    rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].strip())
+                  for r in csv.DictReader(open(kt)) if is_ours(r["Kernel_Name"].split("(")[0].strip()))
+    # group the two decode kernels of one launch: they overlap in time (or touch); the encode kernel is one per launch
+    launches = []
+    for s, e, k in rows:
+        if launches and s < launches[-1][1] + 20000 and k not in launches[-1][2]:
+            launches[-1] = (launches[-1][0], max(e, launches[-1][1]), launches[-1][2] + [k])
+        else:
+            launches.append((s, e, [k]))
+    durs = [e - s for s, e, _ in launches]
+    # bench.py --calib --warmup 2 --steps 5: [calibration, 2 warm-up, 5 timed, 1 re-check]; encode: 1 warm-up, 5 timed, verification decode
+    timed = durs[3:8] if calib_launch else durs[1:6]
+    out["kernel_trace"] = {"launches_seen": len(durs), "steady_state_avg_ns": sum(timed) / max(1, len(timed)), "steady_state_launches": len(timed),
+                           "launch = ": "span of the launch's kernels in the trace (lean + full kernel run side by side)" if what == "decode" else "the encode kernel"}
 log = os.path.join(G, f"{tag}_kt.log")
+bench = None
 if os.path.exists(log):
     for line in open(log):
         if line.startswith("{") and '"metric"' in line:
-            b = json.loads(line)
-            out["bench_line"] = {k: b[k] for k in ("value", "ms_per_step", "config", "roofline", "calibration") if k in b}
-            if "prep" in b["config"]:
-                out["workload"] = {"tiles": b["config"]["prep"]["tiles"], "level": int(b["metric"].split("level ")[1].split(",")[0]),
-                                   "block_size": b["config"]["decoded_bytes_per_gpu"] // b["config"]["blocks_per_gpu"]}
-pm = {}
-for sub, f in (("fetch", "f"), ("write", "w"), ("sq", "s")):
+            bench = json.loads(line)
+            out["bench_line"] = {k: bench[k] for k in ("metric", "value", "ms_per_step", "roofline", "calibration") if k in bench}
+            out["bench_line"]["workload"] = bench["config"]["workload"]
+pm, cal = {}, {}
+for sub, f in (("fetch", "f"), ("write", "w"), ("sq", "s"), ("tcp", "t")):
     p = os.path.join(G, f"{tag}_{sub}", f"{f}_counter_collection.csv")
     if os.path.exists(p):
-        c, n = counters(p)
-        pm.update(c)
-        out.setdefault("dispatches_averaged", {}).update(n)
+        m, c, n = counters(p, calib_launch)
+        pm.update(m); cal.update(c)
+        out.setdefault("launches_averaged", {})[sub] = n
 out["pmc_mean_per_launch"] = {k: round(v, 1) for k, v in pm.items()}
 if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
-    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB. MI355X_MICROARCH.md notes FETCH_SIZE can read
-    # half of a wide coalesced stream on gfx950; this kernel's reads are narrow/gathered, so the raw
-    # value is reported and flagged uncalibrated.
-    cal = out.get("bench_line", {}).get("calibration")
-    fr = fw = 1.0
-    if cal and CALIB.get("FETCH_SIZE") and CALIB.get("WRITE_SIZE"):
-        # known bytes of the calibration launch / what the counters said for it (KiB units)
-        fr = cal["read_bytes"] / (CALIB["FETCH_SIZE"] * 1024)
-        fw = cal["write_bytes"] / (CALIB["WRITE_SIZE"] * 1024)
-        out["calibration"] = {"fetch_factor": round(fr, 4), "write_factor": round(fw, 4), **cal,
-                              "FETCH_SIZE_KiB": CALIB["FETCH_SIZE"], "WRITE_SIZE_KiB": CALIB["WRITE_SIZE"]}
-    out["hbm_traffic_bytes_per_launch"] = {"read": int(pm["FETCH_SIZE"] * 1024 * fr), "write": int(pm["WRITE_SIZE"] * 1024 * fw),
-                                           "total": int(pm["FETCH_SIZE"] * 1024 * fr + pm["WRITE_SIZE"] * 1024 * fw),
-                                           "raw_read": int(pm["FETCH_SIZE"] * 1024), "raw_write": int(pm["WRITE_SIZE"] * 1024),
-                                           "note": "counters scaled by the factors of the calibration launch (16 B/lane streaming "
-                                                   "copy of known size in the same pass)" if cal else "uncalibrated"}
+    raw_r, raw_w = pm["FETCH_SIZE"] * 1024, pm["WRITE_SIZE"] * 1024
+    c = (bench or {}).get("calibration")
+    if c and cal.get("FETCH_SIZE"):
+        out["calibration_launch"] = {**c, "FETCH_SIZE_KiB": cal["FETCH_SIZE"], "WRITE_SIZE_KiB": cal.get("WRITE_SIZE"),
+                                     "stream_read_factor": round(c["read_bytes"] / (cal["FETCH_SIZE"] * 1024), 4),
+                                     "write_factor": round(c["write_bytes"] / (cal["WRITE_SIZE"] * 1024), 4) if cal.get("WRITE_SIZE") else None}
+    read = raw_r * GATHER_FACTOR
+    out["hbm_traffic_bytes_per_launch"] = {"read": int(read), "write": int(raw_w), "total": int(read + raw_w), "raw_read": int(raw_r),
+                                           "read_bracket": [int(raw_r * GATHER_BRACKET[0]), int(raw_r * GATHER_BRACKET[1])],
+                                           "note": "FETCH_SIZE x 1.107 (64-byte-sector gathers and short runs: profiles/r3_gather_calibration.log; bracket x1.0 .. x1.2), "
+                                                   "WRITE_SIZE as counted (exact on the calibration launch)"}
+    if bench:
+        algo = bench["roofline"]["algorithmic_bytes_per_launch"]
+        out["hbm_traffic_bytes_per_launch"]["over_algorithmic"] = round((read + raw_w) / algo, 3)
+        # the table bench.py reads
+        tp = os.path.join(P, "r3_traffic.json")
+        tab = json.load(open(tp)) if os.path.exists(tp) else {}
+        cfg = bench["config"]
+        if what == "decode":
+            lvl = int(bench["metric"].split("level ")[1].split(",")[0])
+            key, wl = f"decode_l{lvl}", {"tiles": cfg["prep"]["tiles"], "block_size": cfg["decoded_bytes_per_gpu"] // cfg["blocks_per_gpu"]}
+        else:
+            lvl = int(bench["metric"].split("level ")[1].split(",")[0])
+            key, wl = f"encode_l{lvl}", {"enc_mib": int(cfg["workload"].split(": ")[1].split(" MiB")[0])}
+        tab[key] = {"workload": wl, "bytes_per_launch": int(read + raw_w), "read": int(read), "write": int(raw_w),
+                    "source": f"profiles/{tag}_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"}
+        json.dump(tab, open(tp, "w"), indent=1)
+if "TCP_TCC_READ_REQ_sum" in pm:
+    out["l1_to_l2_requests_per_launch"] = {"read": int(pm["TCP_TCC_READ_REQ_sum"]), "write": int(pm.get("TCP_TCC_WRITE_REQ_sum", 0)),
+                                           "note": "the CU's L1 hands ~0.1 request per clock to the L2 (profiles/r3_gather_sizes.log: 54 G lane-gathers/s chip-wide "
+                                                   "whatever level serves them): requests x 10 clk / (CUs x clock) bounds the launch from below"}
 json.dump(out, open(os.path.join(P, f"{tag}_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -50,6 +50,22 @@ __device__ __forceinline__ uint32_t e_ld8(const uint8_t* p) { return *p; }
 __device__ __forceinline__ uint32_t e_ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ uint64_t e_ld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ __forceinline__ v4u e_ld128(const uint8_t* p) { v4u v; __builtin_memcpy(&v, p, 16); return v; }
+// 16 bytes at any byte address, fetched DWORD-ALIGNED (four dwords + a fifth, moved into place with v_alignbyte): an unaligned
+// 16-byte gather costs the CU's address / data-return pipeline 4 clocks per lane, an aligned one 1.3
+// (profiles/r3_vmem_test.log), and the encoder's walk is bound by exactly that pipeline (profiles/r3enc_kprof.txt: TD 75 %
+// busy, every ALU under 30 %). `ok` = the 3 bytes in front of p are readable (not the very first bytes of the buffer).
+__device__ __forceinline__ v4u e_ld128_al(const uint8_t* p, bool ok) {
+    const uint32_t sh = ok ? ((uint32_t)(uintptr_t)p & 3u) : 0u;
+    const uint8_t* b = p - sh;
+    const v4u a = e_ld128(b);
+    const uint32_t e = e_ld32(b + 16);
+    v4u r;
+    r.x = __builtin_amdgcn_alignbyte(a.y, a.x, sh);
+    r.y = __builtin_amdgcn_alignbyte(a.z, a.y, sh);
+    r.z = __builtin_amdgcn_alignbyte(a.w, a.z, sh);
+    r.w = __builtin_amdgcn_alignbyte(e, a.w, sh);
+    return r;
+}
 __device__ __forceinline__ uint32_t e_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // LDS traffic between the lanes of the ONE wave of a workgroup: order it (lgkmcnt only). __syncthreads() would also wait
@@ -135,7 +151,7 @@ __device__ __forceinline__ uint32_t prefix16(uint64_t a_lo, uint64_t a_hi, const
 //   GHI: 4-byte words), offsets (GLO), extras
 // HB = log2(head entries), CWB = log2(chain ring entries) or 0 for "head only". depth / sufficient / lazy: the
 // reference's search_depth / sufficient_len / lazy probes (src/lib/zxc_internal.h:965-979), see the table below.
-template <uint32_t HB, uint32_t CWB, bool GHI, uint32_t NC>
+template <uint32_t HB, uint32_t CWB, bool GHI, uint32_t NC, uint32_t U>
 __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src, uint64_t src_size, uint32_t block_size,
                                                  uint8_t* __restrict__ slots, uint32_t slot_stride,
                                                  uint32_t* __restrict__ sizes, uint32_t n_blocks, uint32_t with_checksum,
@@ -213,246 +229,287 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         publish(i, ins, h, d0);
     }
 
+    // The main loop takes ENC_U chunks of 64 positions per iteration (round 3 experiment, kept as a template parameter). A
+    // chunk's work is a chain of dependent steps — head lookup, publish, chain links, candidate bytes from memory, parse,
+    // emission — and a workgroup owns 24-48 KiB of tables, so only 3-6 waves share a CU and every unit is under half busy
+    // (profiles/r3enc_kprof.txt: ~850 instructions, 500 of them scalar, per chunk at ~12 clocks each). With U chunks in flight
+    // the candidate loads of all of them are one memory round trip — measured worth nothing (profiles/r3p_encu.log): the
+    // wave issues in order and its own dependent ALU / LDS / scalar chains are the time, not the memory round trips.
+    // Semantics per chunk are unchanged: its head lookups see every earlier chunk (those of the same iteration included:
+    // lookup and publish alternate chunk by chunk), never its own positions.
+    const bool lowok = b != 0u || D != 0u || ((uint32_t)(uintptr_t)src & 3u) == 0u;  // (3 readable bytes in front of `in`)
     uint32_t c0 = D & ~63u;
-    v4u v_next = {0, 0, 0, 0};  // 16 bytes at every position of the next chunk
+    v4u v_next[U];  // 16 bytes at every position of the next U chunks
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) { const v4u z = {0, 0, 0, 0}; v_next[u] = z; }
     uint32_t c_next = 0xFFFFFFFFu;
-    while (c0 < n) {
-        const uint32_t i = c0 + (uint32_t)lane;
-        const bool can = i < limit && i >= D;
-        uint64_t v = 0, vh = 0;
-        v4u v_cur;
-        if (c_next != c0 && can) v_next = e_ld128(in + i);  // (a long match skipped ahead: the prefetch was for another chunk)
-        {   // request the following chunk's bytes now; they arrive while this chunk is matched, parsed and emitted
-            v_cur = v_next;
-            v = (uint64_t)v_next.x | ((uint64_t)v_next.y << 32);
-            vh = (uint64_t)v_next.z | ((uint64_t)v_next.w << 32);
-            c_next = c0 + 64u;
-            const uint32_t i2 = c_next + (uint32_t)lane;
-            if (i2 < limit) v_next = e_ld128(in + i2);
+    while (c0 < n && !overflow) {
+        uint32_t iA[U], hA[U], d0A[U], lenA[U], distA[U], bkA[U];
+        bool canA[U];
+        uint64_t vA[U], vhA[U];
+        v4u own1A[U], own2A[U];
+        const bool fresh = c_next == c0;
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            iA[u] = c0 + 64u * u + (uint32_t)lane;
+            canA[u] = iA[u] < limit && iA[u] >= D;
+            if (!fresh && canA[u]) v_next[u] = e_ld128(in + iA[u]);  // (a long match skipped ahead: the prefetch was for other chunks)
         }
-        // ---- 1. hash -> head candidate
-        uint32_t h = 0, d0 = 0;
-        if (can) {
-            h = hash_of(v);
-            d0 = (i - (uint32_t)ht[h]) & 0xFFFFu;  // entries hold 16 bits of a position; every candidate is verified
-            if (d0 > i) d0 = 0;                    // (0: none)
+        // request the following chunks' bytes now; they arrive while these are matched, parsed and emitted
+        c_next = c0 + 64u * U;
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            own1A[u] = v_next[u];
+            vA[u] = (uint64_t)v_next[u].x | ((uint64_t)v_next[u].y << 32);
+            vhA[u] = (uint64_t)v_next[u].z | ((uint64_t)v_next[u].w << 32);
+            const uint32_t i2 = c_next + 64u * u + (uint32_t)lane;
+            if (i2 < limit) v_next[u] = e_ld128(in + i2);
+            // my own second 16 bytes: the same for every round of the walk (may reach up to 16 bytes past the block: lengths
+            // are clamped to it below)
+            own2A[u] = e_ld128((canA[u] ? in + iA[u] : in) + 16u);
         }
-        // ---- 2. chain walk, NC candidates per round (zxc_lz77_find_best_match :262-440)
-        uint32_t len = 0, dist = 0, tried = 0, d = d0;
-        // my own second 16 bytes: the same for every round of the walk (may reach up to 16 bytes past the block: lengths are
-        // clamped to it below)
-        const v4u own1 = v_cur;
-        const v4u own2 = e_ld128((can ? in + i : in) + 16u);
+        // ---- 1. hash -> head candidate, then publish: chunk by chunk, so that a chunk's lookup sees the chunks before it
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            uint32_t h = 0, d0 = 0;
+            if (canA[u]) {
+                h = hash_of(vA[u]);
+                d0 = (iA[u] - (uint32_t)ht[h]) & 0xFFFFu;  // entries hold 16 bits of a position; every candidate is verified
+                if (d0 > iA[u]) d0 = 0;                    // (0: none)
+            }
+            hA[u] = h;
+            d0A[u] = d0;
+            __builtin_amdgcn_wave_barrier();
+            enc_lds_fence();
+            publish(iA[u], canA[u], h, d0);
+        }
+        // ---- 2. chain walks of the U chunks, NC candidates per chunk and round (zxc_lz77_find_best_match :262-440)
+        uint32_t triedA[U], dA[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) { lenA[u] = 0; distA[u] = 0; triedA[u] = 0; dA[u] = d0A[u]; }
         for (;;) {
-            const bool act = d != 0u && tried < depth && len < sufficient;
-            if (__ballot(act) == 0ull) break;
-            // a link is still in the ring while no newer position has taken its slot
-            auto next = [&](uint32_t dk, bool want) -> uint32_t {
-                if (!CWB || !want || dk == 0u || dk + 64u - (uint32_t)lane > CW) return 0u;
-                const uint32_t dl = chain[(i - dk) & CWM];
+            bool actA[U];
+            uint64_t anyact = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                actA[u] = dA[u] != 0u && triedA[u] < depth && lenA[u] < sufficient;
+                anyact |= __ballot(actA[u]);
+            }
+            if (anyact == 0ull) break;
+            // a link is still in the ring while no newer position has taken its slot (positions up to the end of this
+            // iteration's last chunk are in the tables)
+            auto next = [&](uint32_t u, uint32_t dk, bool want) -> uint32_t {
+                if (!CWB || !want || dk == 0u || dk + 64u * U - (64u * u + (uint32_t)lane) > CW) return 0u;
+                const uint32_t dl = chain[(iA[u] - dk) & CWM];
                 const uint32_t r = dk + dl;
-                return (dl != 0u && r <= 0xFFFFu && r <= i) ? r : 0u;
+                return (dl != 0u && r <= 0xFFFFu && r <= iA[u]) ? r : 0u;
             };
-            // 32 bytes of every candidate (and my own second 16) are requested together: most matches end inside
-            // them, so a round costs ONE memory round trip; only longer ones enter the extension loop below
-            // (requested by every lane — a lane without that candidate re-reads its own position — so that the
-            // loads are issued back to back and waited for once: a load under a condition is waited for on the spot).
-            // Each candidate's bytes are requested as soon as its distance is known: the further chain links are
+            // 32 bytes of every candidate are requested together, for all chunks: most matches end inside them, so a round
+            // costs ONE memory round trip; only longer ones enter the extension loop below (requested by every lane — a lane
+            // without that candidate re-reads its own position — so that the loads are issued back to back and waited for
+            // once). Each candidate's bytes are requested as soon as its distance is known: the further chain links are
             // dependent LDS reads, and their latency then runs under the first candidate's memory round trip.
-            const uint8_t* pme = can ? in + i : in;
-            uint32_t dk[NC + 1];
-            v4u c1[NC], c2[NC];
-            dk[0] = act ? d : 0u;
-#ifdef ENC_PREFILTER  // experiment (profiles/r3l_encab.log: -6 % at level 3, -10 % at level 5): the 4-byte look costs a second, dependent
-                      // memory round trip per round, and with 6 workgroups per CU the walk is bound by round trips, not by the address pipeline
-            // Round 3: a 4-byte look at every candidate first (the reference's prefilter, src/lib/zxc_compress.c:300-330).
-            // An unaligned 16-byte gather costs the CU's address pipeline 4 clocks per active lane, an unaligned dword
-            // 1.3 (profiles/r3_vmem_test.log), and most candidates of a 13-bit bucket differ within their first four bytes:
-            // the 32 bytes of a candidate are only requested by the lanes whose candidate passed.
-            uint32_t cw[NC];
+            uint32_t dkA[U][NC + 1];
+            v4u c1A[U][NC];
 #pragma unroll
-            for (uint32_t k = 0; k < NC; k++) {
-                cw[k] = e_ld32(pme - dk[k]);
-                dk[k + 1] = next(dk[k], tried + k + 1u < depth);
-            }
-            bool pass[NC];
+            for (uint32_t u = 0; u < U; u++) {
+                const uint8_t* pme = canA[u] ? in + iA[u] : in;
+                dkA[u][0] = actA[u] ? dA[u] : 0u;
 #pragma unroll
-            for (uint32_t k = 0; k < NC; k++) {
-                pass[k] = dk[k] != 0u && cw[k] == (uint32_t)v;
-                c1[k] = own1;   // (a candidate that failed compares as "0 bytes equal" below: mk is forced to 0)
-                c2[k] = own2;
-                if (pass[k]) {
-                    c1[k] = e_ld128(pme - dk[k]);
-                    c2[k] = e_ld128(pme - dk[k] + 16u);
-                }
-            }
+                for (uint32_t k = 0; k < NC; k++) {
+                    #ifdef ENC_ALIGNED_CANDIDATES  // experiment (profiles/r3q_encal.log: +1 % at level 3, -11 % at levels 5-7)
+                    c1A[u][k] = e_ld128_al(pme - dkA[u][k], lowok || iA[u] - dkA[u][k] >= 4u);
 #else
-            bool pass[NC];
-#pragma unroll
-            for (uint32_t k = 0; k < NC; k++) {
-                c1[k] = e_ld128(pme - dk[k]);
-                c2[k] = e_ld128(pme - dk[k] + 16u);
-                dk[k + 1] = next(dk[k], tried + k + 1u < depth);
-                pass[k] = dk[k] != 0u;
-            }
+                    c1A[u][k] = e_ld128(pme - dkA[u][k]);
 #endif
-            const uint64_t o2lo = (uint64_t)own2.x | ((uint64_t)own2.y << 32), o2hi = (uint64_t)own2.z | ((uint64_t)own2.w << 32);
-            uint32_t mk[NC];
-            bool lk[NC];
-            bool anylive = false;
-#pragma unroll
-            for (uint32_t k = 0; k < NC; k++) {
-                mk[k] = pass[k] ? prefix16(v, vh, c1[k]) : 0u;
-                if (mk[k] == 16u) mk[k] += prefix16(o2lo, o2hi, c2[k]);
-                lk[k] = mk[k] == 32u;
-                anylive |= lk[k];
+                    dkA[u][k + 1] = next(u, dkA[u][k], triedA[u] + k + 1u < depth);
+                }
             }
-            // candidates still equal after 32 bytes are extended TOGETHER, 16 bytes per step: one request for my own
-            // bytes and one per live candidate, all in flight at once, so a step costs one memory round trip however
-            // many candidates are still running (the reference extends them one after the other, 8 bytes at a time)
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t i = iA[u];
+                const uint64_t v = vA[u], vh = vhA[u];
+                const uint64_t o2lo = (uint64_t)own2A[u].x | ((uint64_t)own2A[u].y << 32), o2hi = (uint64_t)own2A[u].z | ((uint64_t)own2A[u].w << 32);
+                uint32_t mk[NC];
+                bool lk[NC];
+                bool anylive = false;
+#pragma unroll
+                for (uint32_t k = 0; k < NC; k++) mk[k] = dkA[u][k] ? prefix16(v, vh, c1A[u][k]) : 0u;
+                // the second 16 bytes only for candidates equal over the first 16 (one in five): few lanes, cheap requests
+                bool more = false;
+#pragma unroll
+                for (uint32_t k = 0; k < NC; k++) more |= mk[k] == 16u;
+                if (__ballot(more)) {
+                    const uint8_t* pme = canA[u] ? in + i : in;
+#pragma unroll
+                    for (uint32_t k = 0; k < NC; k++) {
+                        v4u c2 = {0, 0, 0, 0};
+                        if (mk[k] == 16u) c2 = e_ld128(pme - dkA[u][k] + 16u);
+                        if (mk[k] == 16u) mk[k] += prefix16(o2lo, o2hi, c2);
+                    }
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < NC; k++) {
+                    lk[k] = mk[k] == 32u;
+                    anylive |= lk[k];
+                }
+                // candidates still equal after 32 bytes are extended TOGETHER, 16 bytes per step: one request for my own
+                // bytes and one per live candidate, all in flight at once, so a step costs one memory round trip however
+                // many candidates are still running (the reference extends them one after the other, 8 bytes at a time)
+                {
+                    uint32_t L = 32u;
+                    while (anylive) {
+                        if (i + L + 16u > n) {  // block tail: finish bytewise
+#pragma unroll
+                            for (uint32_t k = 0; k < NC; k++)
+                                if (lk[k]) { mk[k] = L; while (i + mk[k] < n && in[i + mk[k]] == in[i - dkA[u][k] + mk[k]]) mk[k]++; lk[k] = false; }
+                            break;
+                        }
+                        const v4u own = e_ld128(in + i + L);
+                        v4u xk[NC];
+#pragma unroll
+                        for (uint32_t k = 0; k < NC; k++) {
+                            xk[k] = own;
+                            if (lk[k]) xk[k] = e_ld128(in + i - dkA[u][k] + L);
+                        }
+                        const uint64_t olo = (uint64_t)own.x | ((uint64_t)own.y << 32), ohi = (uint64_t)own.z | ((uint64_t)own.w << 32);
+                        anylive = false;
+#pragma unroll
+                        for (uint32_t k = 0; k < NC; k++) {
+                            if (lk[k]) { const uint32_t m = prefix16(olo, ohi, xk[k]); if (m < 16u) { mk[k] = L + m; lk[k] = false; } }
+                            anylive |= lk[k];
+                        }
+                        L += 16u;
+                    }
+                    // (the tail path above clamps at n; a 16 / 32-byte prefix that straddles the block end is clamped below)
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < NC; k++)
+                    if (mk[k] > lenA[u]) { lenA[u] = mk[k]; distA[u] = dkA[u][k]; }   // (first = nearest wins ties: smaller offsets, cheaper tokens)
+                triedA[u] += NC;
+                dA[u] = dkA[u][NC];
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t i = iA[u];
+            if (lenA[u] > n - i) lenA[u] = n - i;
+            if (lenA[u] < 5u || !canA[u]) { lenA[u] = 0; distA[u] = 0; }
+            // backward extension available at this position: equal bytes just before both sides (<= 16)
+            // (with every position inserted, position i-1 finds the same candidate itself, so growing backwards changes
+            // next to nothing — identical archive sizes at levels 1-4 in tests/wave_emu — and is kept for the deep levels)
+            uint32_t bk = 0;
+            if (depth > 8u && lenA[u] && i >= 16u && i - distA[u] >= 16u) {
+                const uint64_t y = e_ld64(in + i - 8u) ^ e_ld64(in + i - distA[u] - 8u);
+                const uint64_t y2 = e_ld64(in + i - 16u) ^ e_ld64(in + i - distA[u] - 16u);
+                bk = y ? (uint32_t)(__builtin_clzll(y) >> 3) : (y2 ? 8u + (uint32_t)(__builtin_clzll(y2) >> 3) : 16u);
+            }
+            bkA[u] = bk;
+        }
+
+        // ---- 4. / 5. parse and emit, chunk by chunk (a chunk an earlier match covers entirely selects and emits nothing)
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t cu = c0 + 64u * u;
+            if (cu >= n || overflow) break;
+            const uint32_t i = iA[u], len = lenA[u], dist = distA[u], bk = bkA[u];
+            const uint64_t v = vA[u];
+            const bool can = canA[u];
+            // ---- 4. scalar parse of the chunk: greedy + the level's lazy probes + backward extension
+            uint64_t sel = 0;
+            uint32_t ext_v = 0;  // per selected lane: bytes its match grew backwards
+            uint32_t p = pos > cu ? pos - cu : 0u;
+            uint32_t floor_p = p;  // chunk positions below this are consumed
+            const uint64_t has = __ballot(len >= 5u);  // positions where a match starts
+            const uint32_t pend = (n - cu < 64u) ? n - cu : 64u;
+            while (p < pend) {
+                const uint64_t ahead = has >> p;
+                if (ahead == 0ull) { p = pend; break; }  // nothing left in this chunk: all literals
+                p += (uint32_t)__builtin_ctzll(ahead);
+                if (p >= pend) { p = pend; break; }
+                const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)p);
+                if (lazy >= 1u && L < 128u) {  // (lazy_len_threshold 128)
+                    const uint32_t L1 = (p + 1u < 64u) ? (uint32_t)__builtin_amdgcn_readlane((int)len, (int)(p + 1u)) : 0u;
+                    if (L1 > L + 1u) { p++; continue; }  // a clearly longer match starts one byte later
+                    if (lazy >= 2u) {
+                        const uint32_t L2 = (p + 2u < 64u) ? (uint32_t)__builtin_amdgcn_readlane((int)len, (int)(p + 2u)) : 0u;
+                        if (L2 > L + 2u) { p += 2u; continue; }
+                    }
+                }
+                uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)bk, (int)p);
+                e = e < p - floor_p ? e : p - floor_p;
+                ext_v = ((uint32_t)lane == p) ? e : ext_v;  // (v_cmp + v_cndmask with scalar sources)
+                sel |= 1ull << p;
+                p += L;
+                floor_p = p;
+            }
+            const uint32_t next_pos = cu + p;
+
+            // ---- 5. emit sequences and literals
+            const bool issel = (sel >> lane) & 1ull;
+            const uint64_t below = sel & lt_mask;
+            const int prevlane = below ? 63 - __builtin_clzll(below) : 0;
+            const uint32_t prev_end = __shfl(i + len, prevlane);       // end of the previous selected match (or the carried anchor)
+            const uint32_t lit_start = below ? prev_end : anchor;
+            const uint32_t mstart = i - ext_v;                          // where my match starts after growing backwards
+            const uint32_t ll = issel ? mstart - lit_start : 0u;
+            const uint32_t mlm = issel ? len + ext_v - 5u : 0u;
+            uint32_t eb = 0;
+            if (issel) eb = (ll >= esc ? varint_len(ll - esc) : 0u) + (mlm >= esc ? varint_len(mlm - esc) : 0u);
+            const uint32_t eincl = e_scan_add(eb);
+            const uint32_t etot = (uint32_t)__builtin_amdgcn_readlane((int)eincl, 63);
+            const uint32_t nsel = __popcll(sel);
+            if (seq_count + nsel > max_seq || ext_count + etot > ext_cap) { overflow = true; break; }
+    #ifndef EXP_ENC_NOSTORE  // (experiment, wrong output: the main loop without its emission stores)
+            if (issel) {
+                const uint32_t sidx = seq_count + __popcll(below);
+                if (GHI) {  // 32-bit word LL(8) | ML-5(8) | offset-1(16), src/lib/zxc_compress.c:1907-1913
+                    const uint32_t w = ((ll < 255u ? ll : 255u) << 24) | ((mlm < 255u ? mlm : 255u) << 16) | ((dist - 1u) & 0xFFFFu);
+                    __builtin_memcpy(tok_st + 4u * sidx, &w, 4);
+                } else {
+                    tok_st[sidx] = (uint8_t)(((ll < 15u ? ll : 15u) << 4) | (mlm < 15u ? mlm : 15u));
+                    const uint16_t o16 = (uint16_t)(dist - 1u);
+                    __builtin_memcpy(off_st + 2u * sidx, &o16, 2);
+                }
+                uint8_t* e = ext_st + ext_count + eincl - eb;
+                if (ll >= esc) { put_varint(e, ll - esc); e += varint_len(ll - esc); }
+                if (mlm >= esc) put_varint(e, mlm - esc);
+            }
+    #endif
+            // only the 8-bit / 16-bit offset decision needs the maximum: one ballot instead of a wave reduction
+            if (__ballot(issel && dist > 256u)) max_off = 65535u;
+            else if (sel && max_off == 0u) max_off = 1u;
+            // coverage: selected matches are disjoint and in order. A position is inside a match when it lies before the
+            // end of the last selected match at or below it (or of the match carried into the chunk), or at / after the
+            // (backwards grown) start of the next selected match above it.
+            uint32_t cover_until = pos;
             {
-                uint32_t L = 32u;
-                while (anylive) {
-                    if (i + L + 16u > n) {  // block tail: finish bytewise
-#pragma unroll
-                        for (uint32_t k = 0; k < NC; k++)
-                            if (lk[k]) { mk[k] = L; while (i + mk[k] < n && in[i + mk[k]] == in[i - dk[k] + mk[k]]) mk[k]++; lk[k] = false; }
-                        break;
-                    }
-                    const v4u own = e_ld128(in + i + L);
-                    v4u xk[NC];
-#pragma unroll
-                    for (uint32_t k = 0; k < NC; k++) {
-                        xk[k] = own;
-                        if (lk[k]) xk[k] = e_ld128(in + i - dk[k] + L);
-                    }
-                    const uint64_t olo = (uint64_t)own.x | ((uint64_t)own.y << 32), ohi = (uint64_t)own.z | ((uint64_t)own.w << 32);
-                    anylive = false;
-#pragma unroll
-                    for (uint32_t k = 0; k < NC; k++) {
-                        if (lk[k]) { const uint32_t m = prefix16(olo, ohi, xk[k]); if (m < 16u) { mk[k] = L + m; lk[k] = false; } }
-                        anylive |= lk[k];
-                    }
-                    L += 16u;
-                }
-                // (the tail path above clamps at n; a 16 / 32-byte prefix that straddles the block end is clamped below)
+                const uint32_t endv = issel ? i + len : (below ? prev_end : 0u);
+                cover_until = endv > cover_until ? endv : cover_until;
             }
-#pragma unroll
-            for (uint32_t k = 0; k < NC; k++)
-                if (mk[k] > len) { len = mk[k]; dist = dk[k]; }   // (first = nearest wins ties: smaller offsets, cheaper tokens)
-            tried += NC;
-            d = dk[NC];
-        }
-        if (len > n - i) len = n - i;
-        if (len < 5u) { len = 0; dist = 0; }
-        // backward extension available at this position: equal bytes just before both sides (<= 16)
-        // (with every position inserted, position i-1 finds the same candidate itself, so growing backwards changes
-        // next to nothing — identical archive sizes at levels 1-4 in tests/wave_emu — and is kept for the deep levels)
-        uint32_t bk = 0;
-        if (depth > 8u && len && i >= 16u && i - dist >= 16u) {
-            const uint64_t y = e_ld64(in + i - 8u) ^ e_ld64(in + i - dist - 8u);
-            const uint64_t y2 = e_ld64(in + i - 16u) ^ e_ld64(in + i - dist - 16u);
-            bk = y ? (uint32_t)(__builtin_clzll(y) >> 3) : (y2 ? 8u + (uint32_t)(__builtin_clzll(y2) >> 3) : 16u);
-        }
-        // ---- 3. publish this chunk's positions: lookups above saw only earlier chunks
-        __builtin_amdgcn_wave_barrier();
-        enc_lds_fence();
-        publish(i, can, h, d0);
-
-        // ---- 4. scalar parse of the chunk: greedy + the level's lazy probes + backward extension
-        uint64_t sel = 0;
-        uint32_t ext_v = 0;  // per selected lane: bytes its match grew backwards
-        uint32_t p = pos > c0 ? pos - c0 : 0u;
-        uint32_t floor_p = p;  // chunk positions below this are consumed
-        const uint64_t has = __ballot(len >= 5u);  // positions where a match starts
-        const uint32_t pend = (n - c0 < 64u) ? n - c0 : 64u;
-        while (p < pend) {
-            const uint64_t ahead = has >> p;
-            if (ahead == 0ull) { p = pend; break; }  // nothing left in this chunk: all literals
-            p += (uint32_t)__builtin_ctzll(ahead);
-            if (p >= pend) { p = pend; break; }
-            const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)p);
-            if (lazy >= 1u && L < 128u) {  // (lazy_len_threshold 128)
-                const uint32_t L1 = (p + 1u < 64u) ? (uint32_t)__builtin_amdgcn_readlane((int)len, (int)(p + 1u)) : 0u;
-                if (L1 > L + 1u) { p++; continue; }  // a clearly longer match starts one byte later
-                if (lazy >= 2u) {
-                    const uint32_t L2 = (p + 2u < 64u) ? (uint32_t)__builtin_amdgcn_readlane((int)len, (int)(p + 2u)) : 0u;
-                    if (L2 > L + 2u) { p += 2u; continue; }
-                }
+            const uint64_t above = sel & ~(lt_mask | (1ull << lane));
+            const int nextlane = above ? __builtin_ctzll(above) : 0;
+            const uint32_t next_start = __shfl(mstart, nextlane);
+            const bool in_next = above != 0ull && i >= next_start;
+            // literal = in range, not inside a match, and already passed by the parse
+            const bool islit = i < n && i >= cover_until && i < next_pos && !in_next;
+            const uint64_t litmask = __ballot(islit);
+            // (the byte is already here: low byte of the 16 fetched for this position; only the block's last 16
+            // positions, which never start a match, were not fetched)
+    #ifndef EXP_ENC_NOSTORE
+            if (islit) lit_out[lit_count + __popcll(litmask & lt_mask)] = can ? (uint8_t)v : (uint8_t)e_ld8(in + i);
+    #endif
+            lit_count += __popcll(litmask);
+            seq_count += nsel;
+            ext_count += etot;
+            if (sel) {
+                const int last = 63 - __builtin_clzll(sel);
+                anchor = __shfl(i + len, last);
             }
-            uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)bk, (int)p);
-            e = e < p - floor_p ? e : p - floor_p;
-            ext_v = ((uint32_t)lane == p) ? e : ext_v;  // (v_cmp + v_cndmask with scalar sources)
-            sel |= 1ull << p;
-            p += L;
-            floor_p = p;
+            pos = next_pos;
         }
-        const uint32_t next_pos = c0 + p;
-
-        // ---- 5. emit sequences and literals
-        const bool issel = (sel >> lane) & 1ull;
-        const uint64_t below = sel & lt_mask;
-        const int prevlane = below ? 63 - __builtin_clzll(below) : 0;
-        const uint32_t prev_end = __shfl(i + len, prevlane);       // end of the previous selected match (or the carried anchor)
-        const uint32_t lit_start = below ? prev_end : anchor;
-        const uint32_t mstart = i - ext_v;                          // where my match starts after growing backwards
-        const uint32_t ll = issel ? mstart - lit_start : 0u;
-        const uint32_t mlm = issel ? len + ext_v - 5u : 0u;
-        uint32_t eb = 0;
-        if (issel) eb = (ll >= esc ? varint_len(ll - esc) : 0u) + (mlm >= esc ? varint_len(mlm - esc) : 0u);
-        const uint32_t eincl = e_scan_add(eb);
-        const uint32_t etot = (uint32_t)__builtin_amdgcn_readlane((int)eincl, 63);
-        const uint32_t nsel = __popcll(sel);
-        if (seq_count + nsel > max_seq || ext_count + etot > ext_cap) { overflow = true; break; }
-#ifndef EXP_ENC_NOSTORE  // (experiment, wrong output: the main loop without its emission stores)
-        if (issel) {
-            const uint32_t sidx = seq_count + __popcll(below);
-            if (GHI) {  // 32-bit word LL(8) | ML-5(8) | offset-1(16), src/lib/zxc_compress.c:1907-1913
-                const uint32_t w = ((ll < 255u ? ll : 255u) << 24) | ((mlm < 255u ? mlm : 255u) << 16) | ((dist - 1u) & 0xFFFFu);
-                __builtin_memcpy(tok_st + 4u * sidx, &w, 4);
-            } else {
-                tok_st[sidx] = (uint8_t)(((ll < 15u ? ll : 15u) << 4) | (mlm < 15u ? mlm : 15u));
-                const uint16_t o16 = (uint16_t)(dist - 1u);
-                __builtin_memcpy(off_st + 2u * sidx, &o16, 2);
-            }
-            uint8_t* e = ext_st + ext_count + eincl - eb;
-            if (ll >= esc) { put_varint(e, ll - esc); e += varint_len(ll - esc); }
-            if (mlm >= esc) put_varint(e, mlm - esc);
-        }
-#endif
-        // only the 8-bit / 16-bit offset decision needs the maximum: one ballot instead of a wave reduction
-        if (__ballot(issel && dist > 256u)) max_off = 65535u;
-        else if (sel && max_off == 0u) max_off = 1u;
-        // coverage: selected matches are disjoint and in order. A position is inside a match when it lies before the
-        // end of the last selected match at or below it (or of the match carried into the chunk), or at / after the
-        // (backwards grown) start of the next selected match above it.
-        uint32_t cover_until = pos;
-        {
-            const uint32_t endv = issel ? i + len : (below ? prev_end : 0u);
-            cover_until = endv > cover_until ? endv : cover_until;
-        }
-        const uint64_t above = sel & ~(lt_mask | (1ull << lane));
-        const int nextlane = above ? __builtin_ctzll(above) : 0;
-        const uint32_t next_start = __shfl(mstart, nextlane);
-        const bool in_next = above != 0ull && i >= next_start;
-        // literal = in range, not inside a match, and already passed by the parse
-        const bool islit = i < n && i >= cover_until && i < next_pos && !in_next;
-        const uint64_t litmask = __ballot(islit);
-        // (the byte is already here: low byte of the 16 fetched for this position; only the block's last 16
-        // positions, which never start a match, were not fetched)
-#ifndef EXP_ENC_NOSTORE
-        if (islit) lit_out[lit_count + __popcll(litmask & lt_mask)] = can ? (uint8_t)v : (uint8_t)e_ld8(in + i);
-#endif
-        lit_count += __popcll(litmask);
-        seq_count += nsel;
-        ext_count += etot;
-        if (sel) {
-            const int last = 63 - __builtin_clzll(sel);
-            anchor = __shfl(i + len, last);
-        }
-        pos = next_pos;
-        // a match reaching past this chunk: skip the chunks it covers entirely
-        c0 += 64u;
+        // a match reaching past these chunks: skip the chunks it covers entirely
+        c0 += 64u * U;
         if (pos > c0) c0 = pos & ~63u;
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -679,12 +736,16 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
 //     5     2^13     2^14        18       256          2      GLO
 //     6     2^13     2^14        33       256          2      GLO   (+ PivCo literals; lazy parse, not the reference's optimal parse)
 //     7     2^13     2^14        66       256          2      GLO
+#ifndef ENC_U
+#define ENC_U 1u   // chunks of 64 positions in flight per loop iteration (A/B, profiles/r3p_encu.log: 1 / 2 / 3 / 4 all within 2 % at
+                   // level 3 — a wave issues in order, only the memory round trips overlap — and 1 keeps the archives of round 2 byte for byte)
+#endif
 #define ZXC_ENCODE_ENTRY(name, hb, cwb, ghi, waves, nc)                                                                    \
     extern "C" __global__ void __launch_bounds__(64, waves) name(                                                      \
         const uint8_t* __restrict__ src, uint64_t src_size, uint32_t block_size, uint8_t* __restrict__ slots,          \
         uint32_t slot_stride, uint32_t* __restrict__ sizes, uint32_t n_blocks, uint32_t with_checksum, uint32_t depth, \
         uint32_t sufficient, uint32_t lazy, uint32_t dict_size, uint8_t* __restrict__ huf_scratch, uint32_t huf) {     \
-        encode_one_block<hb, cwb, ghi, nc>(src, src_size, block_size, slots, slot_stride, sizes, n_blocks, with_checksum,  \
+        encode_one_block<hb, cwb, ghi, nc, ENC_U>(src, src_size, block_size, slots, slot_stride, sizes, n_blocks, with_checksum,  \
                                        depth, sufficient, lazy, dict_size, huf_scratch, huf);                          \
     }
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l1, 12u, 0u, true, 5, 3u)    // level 1 (A/B: one candidate per round instead of three: -3 %)
