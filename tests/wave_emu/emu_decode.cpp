@@ -36,14 +36,6 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
                                               nullptr, 0u, dptr, dict_size, dict_huf);
             }, b, n_jobs, 64);
         }
-    } else if (verify_trailer) {
-        for (uint32_t b = 0; b < n_jobs; b++) {
-            memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));
-            emu::run_wave([&] {
-                zxc_decode_blocks_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, 4u, scratch.data(),
-                                         stride, 0u, busy.data(), n_slots, nullptr, 0u, nullptr);
-            }, b, n_jobs, 64);
-        }
     } else {
         // the two-pass launch of zxc_hip_shim.hip: the lean kernel over every block (in a launch order that is not the
         // identity), then the full kernel, a fixed grid walking the list of blocks the lean kernel handed over
@@ -51,12 +43,12 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
         for (uint32_t b = 0; b < n_jobs; b++) {
             order[b] = n_jobs - 1u - b;
             // (what zxc_order_scatter_kernel appends, by the same predicate)
-            if (block_needs_full_kernel(c.data() + 4096 + jobs[order[b]].comp_off, jobs[order[b]].comp_size)) list[2u + list[0]++] = b;
+            if (block_needs_full_kernel(c.data() + 4096 + jobs[order[b]].comp_off, jobs[order[b]].comp_size, verify_trailer ? 4u : 0u)) list[2u + list[0]++] = b;
         }
         for (uint32_t b = 0; b < n_jobs; b++) {
             memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));
             emu::run_wave([&] {
-                zxc_decode_blocks_lean_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, order.data(), 0u);
+                zxc_decode_blocks_lean_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, order.data(), 0u, verify_trailer ? 4u : 0u);
             }, b, n_jobs, 64);
         }
         emu_last_deferred = list[0];
@@ -64,7 +56,7 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
         for (uint32_t b = 0; b < grid; b++) {
             memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));
             emu::run_wave([&] {
-                zxc_decode_blocks_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, 0u, scratch.data(),
+                zxc_decode_blocks_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, verify_trailer ? 4u : 0u, scratch.data(),
                                          stride, 0u, busy.data(), n_slots, order.data(), 0u, list.data());
             }, b, grid, 64);
         }

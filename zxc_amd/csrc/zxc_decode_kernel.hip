@@ -1322,10 +1322,10 @@ zxc_decode_blocks_dict_kernel(const uint8_t* __restrict__ comp, const zxc_dev_jo
 // Which kernel decodes a block: the lean one unless it is a GLO block with a coded literal / token section (every other
 // block, malformed ones included, gets its verdict from the lean kernel). ONE predicate for the lean kernel and for the
 // pass that builds the full kernel's list: a block must be taken by exactly one of them.
-__device__ __forceinline__ bool block_needs_full_kernel(const uint8_t* __restrict__ src, uint32_t src_sz) {
+__device__ __forceinline__ bool block_needs_full_kernel(const uint8_t* __restrict__ src, uint32_t src_sz, uint32_t trailer_bytes) {
     if (src_sz < 8u + 12u) return false;
     const uint32_t comp_sz = ld32(src + 3);
-    if (ld8(src) != 1u || comp_sz < 12u || (uint64_t)8u + comp_sz > src_sz) return false;
+    if (ld8(src) != 1u || comp_sz < 12u || (uint64_t)8u + comp_sz + trailer_bytes > src_sz) return false;
     return ld8(src + 16) != 0u || ld8(src + 17) != 0u;
 }
 
@@ -1336,7 +1336,7 @@ __device__ __forceinline__ bool block_needs_full_kernel(const uint8_t* __restric
 extern "C" __global__ void __launch_bounds__(64, LEAN_WAVES_PER_SIMD)
 zxc_decode_blocks_lean_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
                               uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,
-                              const uint32_t* __restrict__ order, uint32_t cap_override) {
+                              const uint32_t* __restrict__ order, uint32_t cap_override, uint32_t trailer_bytes) {
     __shared__ LeanLds L;
     const int lane = threadIdx.x;
     if (blockIdx.x >= n_jobs) return;
@@ -1348,14 +1348,16 @@ zxc_decode_blocks_lean_kernel(const uint8_t* __restrict__ comp, const zxc_dev_jo
     const uint8_t* src = comp + comp_off;
     uint8_t* dst = out + jobs[b].out_off;
     int rc;
-    if (uni(block_needs_full_kernel(src, src_sz) ? 1u : 0u)) return;  // on the full kernel's list (zxc_order_scatter_kernel)
+    if (uni(block_needs_full_kernel(src, src_sz, trailer_bytes) ? 1u : 0u)) return;  // on the full kernel's list (zxc_order_scatter_kernel)
     if (src_sz < 8u) {
         rc = E_SRC_TOO_SMALL;
     } else {
         const uint32_t type = uni(ld8(src));
         const uint32_t comp_sz = uni(ld32(src + 3));
-        if ((uint64_t)8u + comp_sz > src_sz) {
+        if ((uint64_t)8u + comp_sz + trailer_bytes > src_sz) {
             rc = E_SRC_TOO_SMALL;
+        } else if (trailer_bytes && wave_checksum32(src + 8, comp_sz, lane) != uni(ld32(src + 8 + comp_sz))) {
+            rc = E_BAD_CHECKSUM;  // per-block checksum of the compressed payload (zxc_decompress.c:1662-1666)
         } else if (type == 1u || type == 2u) {
             rc = decode_lz_block_lean(src + 8, comp_sz, type == 2u, dst, out_len, cap, L, lane);
         } else if (type == 0u) {  // RAW: stored bytes
@@ -1420,7 +1422,7 @@ zxc_order_hist_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __r
 extern "C" __global__ void __launch_bounds__(256)
 zxc_order_scatter_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
                          uint32_t block_size, uint32_t* __restrict__ hist, uint32_t* __restrict__ order,
-                         uint32_t* __restrict__ list) {
+                         uint32_t* __restrict__ list, uint32_t trailer_bytes) {
     __shared__ uint32_t cnt[64], base[64];
     if (threadIdx.x < 64u) cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -1440,6 +1442,6 @@ zxc_order_scatter_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* 
     if (i < n_jobs) {
         order[base[bk] + rank] = i;
         // two-pass launches: positions (in launch order) of the blocks the full kernel decodes; list[0] = their number, list[1] = 0
-        if (list && block_needs_full_kernel(comp + jobs[i].comp_off, jobs[i].comp_size)) list[2u + atomicAdd(list, 1u)] = base[bk] + rank;
+        if (list && block_needs_full_kernel(comp + jobs[i].comp_off, jobs[i].comp_size, trailer_bytes)) list[2u + atomicAdd(list, 1u)] = base[bk] + rank;
     }
 }

@@ -16,11 +16,11 @@ extern "C" __global__ void zxc_decode_blocks_kernel(const uint8_t* comp, const z
                                                     uint32_t cap_override, uint32_t* list);
 extern "C" __global__ void zxc_decode_blocks_lean_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                          uint8_t* out, int32_t* status, uint32_t block_size,
-                                                         const uint32_t* order, uint32_t cap_override);
+                                                         const uint32_t* order, uint32_t cap_override, uint32_t trailer_bytes);
 extern "C" __global__ void zxc_order_hist_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                  uint32_t block_size, uint32_t* hist);
 extern "C" __global__ void zxc_order_scatter_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
-                                                    uint32_t block_size, uint32_t* hist, uint32_t* order, uint32_t* list);
+                                                    uint32_t block_size, uint32_t* hist, uint32_t* order, uint32_t* list, uint32_t trailer_bytes);
 extern "C" __global__ void zxc_decode_blocks_dict_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                          uint8_t* out, int32_t* status, uint32_t block_size,
                                                          uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride,
@@ -220,13 +220,13 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
         pool.stride = stride;
     }
     const uint32_t n_slots = pool.n_slots;
-    // Two kernels for archives without dictionary and checksums: the LEAN kernel (more waves per SIMD, raw sections only)
+    // Two kernels for archives without a dictionary: the LEAN kernel (more waves per SIMD, raw sections only)
     // over every block, and the full kernel over the list of blocks with a coded section, which the launch-order pass builds
     // from the block headers. The two run side by side: the full kernel on a helper stream forked from the caller's and joined
     // back into it (event fork / join: capturable, no host synchronisation). Per-stream buffer:
     // [128 u32 histogram + cursors | list: count, next, n entries | order[n]]; heaviest-first dispatch order (a launch ends when its slowest
     // block ends).
-    const bool two_pass = !d_dict && !d_dict_huf && !verify_trailer && !(g_debug_flags & 0x40000000u);
+    const bool two_pass = !d_dict && !d_dict_huf && !(g_debug_flags & 0x40000000u);
     const bool want_order = two_pass || (n_jobs > max_slots && !(g_debug_flags & 0x80000000u));
     uint32_t* order = NULL;
     uint32_t* list = NULL;
@@ -260,7 +260,7 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
                 hipLaunchKernelGGL(zxc_order_hist_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
                                    d_jobs, n_jobs, block_size, buf);
                 hipLaunchKernelGGL(zxc_order_scatter_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream,
-                                   (const uint8_t*)d_comp, d_jobs, n_jobs, block_size, buf, buf + 130 + n_jobs, list);
+                                   (const uint8_t*)d_comp, d_jobs, n_jobs, block_size, buf, buf + 130 + n_jobs, list, verify_trailer ? 4u : 0u);
                 order = buf + 130 + n_jobs;
             }
         }
@@ -278,11 +278,12 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
         // (if the fork fails the full kernel simply runs behind the lean one on the caller's stream)
         hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(n_jobs < max_slots ? n_jobs : max_slots), dim3(64), 0,
                            forked ? o.aux : (hipStream_t)stream, (const uint8_t*)d_comp, d_jobs, n_jobs, (uint8_t*)d_out, d_status,
-                           block_size, 0u, pool.scratch, stride, g_debug_flags, pool.busy, n_slots, order, cap_override, list);
+                           block_size, verify_trailer ? 4u : 0u, pool.scratch, stride, g_debug_flags, pool.busy, n_slots, order,
+                           cap_override, list);
         if (forked && hipEventRecord(o.join, o.aux) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
 #endif
         hipLaunchKernelGGL(zxc_decode_blocks_lean_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
-                           d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, order, cap_override);
+                           d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, order, cap_override, verify_trailer ? 4u : 0u);
         if (forked && hipStreamWaitEvent((hipStream_t)stream, o.join, 0) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
     } else
         hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
