@@ -11,33 +11,38 @@
 namespace emu {
 namespace {
 constexpr size_t STACK = 1u << 20;
-struct State {
-    ucontext_t sched;
+constexpr int MAXW = 8;  // wavefronts per workgroup (512 threads)
+struct WLog { uintptr_t addr; uint8_t size; bool is_or; uint8_t data[16]; };
+struct WaveSt {
     ucontext_t ctx[W];
-    char* stack[W];
+    char* stack[W] = {};
     bool done[W];
-    int cur = 0, live = 0, arrived = 0;
+    int live = 0, arrived = 0;
     unsigned gen = 0;
     uint64_t in[W], snap[2][W], act[2], arrived_mask = 0;
     int tag[W];
+    // buffered LDS writes (emu_lds_hooks.h): per lane, applied at the wave's next rendezvous
+    std::vector<WLog> wlog[W];
+};
+struct State {
+    ucontext_t sched;
+    WaveSt wv[MAXW];
+    int n_waves = 1, cw = 0, cur = 0;
+    int wg_live = 0, wg_arrived = 0;  // workgroup barrier (s_barrier): lanes of all waves
+    unsigned wg_gen = 0;
     Idx bid{0, 0, 0}, gdim{1, 1, 1};
-    int n_lanes = W;
     std::function<void()> body;
     uint64_t clk = 0;
-    bool stacks_ready = false;
-    // buffered LDS writes (emu_lds_hooks.h): per lane, applied at the next rendezvous
-    struct WLog { uintptr_t addr; uint8_t size; bool is_or; uint8_t data[16]; };
-    std::vector<WLog> wlog[W];
     std::vector<uint8_t> shadow;  // per LDS byte of this interval: 0 = untouched, 1..64 = plain store by lane-1, 65 = or
 } S;
 extern "C" char __start_emu_lds[], __stop_emu_lds[];
 
-void commit_lds() {
+void commit_lds(WaveSt& V) {
     const uintptr_t lo = (uintptr_t)__start_emu_lds, hi = (uintptr_t)__stop_emu_lds;
     if (S.shadow.size() != hi - lo) S.shadow.assign(hi - lo, 0);
     std::vector<uintptr_t> touched;
     for (int l = 0; l < W; l++) {
-        for (const auto& w : S.wlog[l]) {
+        for (const auto& w : V.wlog[l]) {
             if (w.addr < lo || w.addr + w.size > hi) { fprintf(stderr, "wave_emu: LDS hook on a non-LDS address\n"); abort(); }
             for (unsigned k = 0; k < w.size; k++) {
                 uint8_t& sh = S.shadow[w.addr + k - lo];
@@ -61,59 +66,62 @@ void commit_lds() {
                 }
             }
         }
-        S.wlog[l].clear();
+        V.wlog[l].clear();
     }
     for (uintptr_t t : touched) S.shadow[t] = 0;
 }
 
-void release() {
-    commit_lds();
-    const unsigned g = S.gen + 1u;
+void release(WaveSt& V) {
+    commit_lds(V);
+    const unsigned g = V.gen + 1u;
     int t = -1;
     for (int i = 0; i < W; i++) {
-        if ((S.arrived_mask >> i) & 1) {
-            if (t < 0) t = S.tag[i];
-            else if (t != S.tag[i]) {
+        if ((V.arrived_mask >> i) & 1) {
+            if (t < 0) t = V.tag[i];
+            else if (t != V.tag[i]) {
                 fprintf(stderr, "wave_emu: lanes meet at different cross-lane operations (source lines %d and %d): "
-                                "a cross-lane operation sits inside divergent control flow\n", t, S.tag[i]);
+                                "a cross-lane operation sits inside divergent control flow\n", t, V.tag[i]);
                 abort();
             }
-            S.snap[g & 1][i] = S.in[i];
+            V.snap[g & 1][i] = V.in[i];
         } else {
-            S.snap[g & 1][i] = 0;
+            V.snap[g & 1][i] = 0;
         }
     }
-    S.act[g & 1] = S.arrived_mask;
-    S.arrived = 0;
-    S.arrived_mask = 0;
-    S.gen = g;
+    V.act[g & 1] = V.arrived_mask;
+    V.arrived = 0;
+    V.arrived_mask = 0;
+    V.gen = g;
 }
 
 void trampoline() {
     S.body();
-    S.done[S.cur] = true;
-    S.live--;
-    if (S.live == 0) commit_lds();
-    if (S.arrived > 0 && S.arrived == S.live) release();
-    swapcontext(&S.ctx[S.cur], &S.sched);
+    WaveSt& V = S.wv[S.cw];
+    V.done[S.cur] = true;
+    V.live--;
+    S.wg_live--;
+    if (V.live == 0) commit_lds(V);
+    if (V.arrived > 0 && V.arrived == V.live) release(V);
+    if (S.wg_arrived > 0 && S.wg_arrived == S.wg_live) { S.wg_arrived = 0; S.wg_gen++; }  // (s_barrier does not wait for ended waves)
+    swapcontext(&V.ctx[S.cur], &S.sched);
 }
 }  // namespace
 
 void lds_write(void* p, const void* data, unsigned size, bool is_or) {
-    State::WLog w;
+    WLog w;
     w.addr = (uintptr_t)p;
     w.size = (uint8_t)size;
     w.is_or = is_or;
     memcpy(w.data, data, size);
     if ((w.addr & (size - 1u)) != 0) { fprintf(stderr, "wave_emu: misaligned %u-byte LDS store\n", size); abort(); }
-    S.wlog[S.cur].push_back(w);
+    S.wv[S.cw].wlog[S.cur].push_back(w);
 }
 void lds_read(const void* p, void* out, unsigned size) {
     const uintptr_t a = (uintptr_t)p;
     if ((a & (size - 1u)) != 0) { fprintf(stderr, "wave_emu: misaligned %u-byte LDS load\n", size); abort(); }
     memcpy(out, p, size);
     uint8_t* o = (uint8_t*)out;
-    for (const auto& w : S.wlog[S.cur]) {  // the lane's own earlier writes of this interval, in order
+    for (const auto& w : S.wv[S.cw].wlog[S.cur]) {  // the lane's own earlier writes of this interval, in order
         if (w.addr + w.size <= a || a + size <= w.addr) continue;
         for (unsigned k = 0; k < w.size; k++) {
             const uintptr_t b = w.addr + k;
@@ -124,7 +132,7 @@ void lds_read(const void* p, void* out, unsigned size) {
     }
 }
 int lane() { return S.cur; }
-Idx tid() { return Idx{(unsigned)S.cur, 0, 0}; }
+Idx tid() { return Idx{(unsigned)(S.cw * W + S.cur), 0, 0}; }
 Idx bid() { return S.bid; }
 Idx gdim() { return S.gdim; }
 uint64_t clock64() { return S.clk += 7; }
@@ -134,46 +142,71 @@ void fail(const char* what, int tag) {
 }
 
 const uint64_t* sync(uint64_t v, int tag, uint64_t* active) {
-    const int me = S.cur;
-    S.in[me] = v;
-    S.tag[me] = tag;
-    S.arrived_mask |= 1ull << me;
-    S.arrived++;
-    const unsigned g = S.gen;
-    if (S.arrived == S.live) release();
-    while (S.gen == g) swapcontext(&S.ctx[me], &S.sched);
-    // a lane can be at most one rendezvous ahead of the slowest one, so generation g+1 is still intact
-    *active = S.act[(g + 1u) & 1];
-    return S.snap[(g + 1u) & 1];
+    const int me = S.cur, w = S.cw;
+    WaveSt& V = S.wv[w];
+    V.in[me] = v;
+    V.tag[me] = tag;
+    V.arrived_mask |= 1ull << me;
+    V.arrived++;
+    const unsigned g = V.gen;
+    if (V.arrived == V.live) release(V);
+    while (V.gen == g) swapcontext(&V.ctx[me], &S.sched);
+    // a lane can be at most one rendezvous ahead of the slowest one of its wave, so generation g+1 is still intact
+    *active = V.act[(g + 1u) & 1];
+    return V.snap[(g + 1u) & 1];
 }
 
-// Runs `body` once per lane of one wavefront (workgroup of n_lanes <= 64 threads) as block `block` of `grid`.
+// s_barrier / __syncthreads: a rendezvous of the lane's own wave first (its LDS writes are applied, divergence inside the wave
+// is caught), then of every live lane of the workgroup. Waves may arrive from different call sites, as on the hardware.
+void wg_barrier(int tag) {
+    barrier(tag);
+    if (S.n_waves == 1) return;
+    const int me = S.cur, w = S.cw;
+    const unsigned g = S.wg_gen;
+    S.wg_arrived++;
+    if (S.wg_arrived == S.wg_live) { S.wg_arrived = 0; S.wg_gen++; }
+    while (S.wg_gen == g) swapcontext(&S.wv[w].ctx[me], &S.sched);
+}
+
+// Runs `body` once per thread of one workgroup of n_lanes <= 512 threads (wavefronts of 64) as block `block` of `grid`.
 void run_wave(const std::function<void()>& body, unsigned block, unsigned grid, int n_lanes) {
-    if (!S.stacks_ready) {
-        for (int i = 0; i < W; i++) S.stack[i] = (char*)malloc(STACK);
-        S.stacks_ready = true;
-    }
+    const int nw = (n_lanes + W - 1) / W;
+    if (nw < 1 || nw > MAXW) fail("workgroup size", n_lanes);
     S.body = body;
     S.bid = Idx{block, 0, 0};
     S.gdim = Idx{grid, 1, 1};
-    S.n_lanes = n_lanes;
-    S.live = n_lanes;
-    S.arrived = 0;
-    S.arrived_mask = 0;
-    for (int i = 0; i < W; i++) S.done[i] = i >= n_lanes;
-    for (int i = 0; i < n_lanes; i++) {
-        getcontext(&S.ctx[i]);
-        S.ctx[i].uc_stack.ss_sp = S.stack[i];
-        S.ctx[i].uc_stack.ss_size = STACK;
-        S.ctx[i].uc_link = &S.sched;
-        makecontext(&S.ctx[i], (void (*)())trampoline, 0);
-    }
-    while (S.live > 0) {
-        for (int i = 0; i < n_lanes; i++) {
-            if (S.done[i]) continue;
-            S.cur = i;
-            swapcontext(&S.sched, &S.ctx[i]);
+    S.n_waves = nw;
+    S.wg_live = n_lanes;
+    S.wg_arrived = 0;
+    for (int w = 0; w < nw; w++) {
+        WaveSt& V = S.wv[w];
+        const int nl = w + 1 < nw ? W : n_lanes - W * (nw - 1);
+        V.live = nl;
+        V.arrived = 0;
+        V.arrived_mask = 0;
+        for (int i = 0; i < W; i++) V.done[i] = i >= nl;
+        for (int i = 0; i < nl; i++) {
+            if (!V.stack[i]) V.stack[i] = (char*)malloc(STACK);
+            getcontext(&V.ctx[i]);
+            V.ctx[i].uc_stack.ss_sp = V.stack[i];
+            V.ctx[i].uc_stack.ss_size = STACK;
+            V.ctx[i].uc_link = &S.sched;
+            makecontext(&V.ctx[i], (void (*)())trampoline, 0);
         }
+    }
+    for (;;) {
+        bool any = false;
+        for (int w = 0; w < nw; w++) {
+            WaveSt& V = S.wv[w];
+            for (int i = 0; i < W; i++) {
+                if (V.done[i]) continue;
+                any = true;
+                S.cw = w;
+                S.cur = i;
+                swapcontext(&S.sched, &V.ctx[i]);
+            }
+        }
+        if (!any) break;
     }
 }
 }  // namespace emu

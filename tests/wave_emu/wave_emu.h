@@ -1,4 +1,4 @@
-// wave_emu.h — lock-step emulation of one gfx950 wavefront on the CPU (test infrastructure).
+// wave_emu.h — lock-step emulation of the gfx950 wavefronts of one workgroup on the CPU (test infrastructure).
 //
 // The device sources under zxc_amd/csrc are compiled unchanged for x86 with this header standing
 // in for <hip/hip_runtime.h>: each of the 64 lanes of a wavefront is a fiber (ucontext), and every
@@ -55,6 +55,7 @@ inline uint64_t ballot(bool p, int tag) {
     return m;
 }
 inline void barrier(int tag) { uint64_t act; (void)sync(0, tag, &act); }
+void wg_barrier(int tag);  // s_barrier: every live lane of the workgroup (wave_emu.cpp)
 // v_mov_b32_dpp semantics for the controls the kernels use (gfx9 DPP): row_shr:n, row_shl:n, row_ror:n,
 // wave_shr:1 / wave_shl:1, row_bcast:15, row_bcast:31, quad_perm, row_mirror, row_half_mirror.
 inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl, int tag) {
@@ -136,12 +137,12 @@ template <typename T> inline T ntload(const void* p) { T v; memcpy(&v, p, sizeof
 #define __builtin_amdgcn_fence(order, scope) emu::barrier(__LINE__)
 #define __builtin_amdgcn_wave_barrier() emu::barrier(__LINE__)
 #define __builtin_amdgcn_s_waitcnt(n) emu::barrier(__LINE__)
-#define __builtin_amdgcn_s_barrier() emu::barrier(__LINE__)
+#define __builtin_amdgcn_s_barrier() emu::wg_barrier(__LINE__)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_nontemporal_load(p) emu::ntload<std::remove_cv_t<std::remove_reference_t<decltype(*(p))>>>((const void*)(p))
 #define address_space(n)   /* __attribute__((address_space(1))) pointers are ordinary pointers here */
-#define __syncthreads() emu::barrier(__LINE__)
+#define __syncthreads() emu::wg_barrier(__LINE__)
 #define __shfl(v, l) emu::shfl((uint32_t)(v), (int)(l), __LINE__)
 #define __shfl_up(v, d) emu::shfl_up((uint32_t)(v), (unsigned)(d), __LINE__)
 #define __shfl_xor(v, m) emu::shfl_xor((uint32_t)(v), (int)(m), __LINE__)

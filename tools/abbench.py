@@ -12,7 +12,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     level = int(os.environ.get("AB_LEVEL", "3"))
     dev = torch.device("cuda", 0)
     comp = np.load(f"{TMP}/comp.npy"); sizes = np.load(f"{TMP}/sizes.npy"); want = np.load(f"{TMP}/want.npy")
-    n = sizes.size
+    n = min(sizes.size, int(os.environ.get("AB_MAXBLOCKS", "1000000000")))  # (AB_MAXBLOCKS: the first blocks only)
+    sizes = sizes[:n]; want = want[:n * 65536]
     jobs = np.zeros(n, dtype=zxc_amd.api.JOB_DTYPE)
     jobs["comp_size"] = sizes
     jobs["comp_off"] = np.concatenate([[0], np.cumsum(sizes.astype(np.uint64))[:-1]])

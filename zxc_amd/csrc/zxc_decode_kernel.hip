@@ -414,6 +414,7 @@ __device__ __forceinline__ uint32_t parse_varints(const uint8_t* ext, uint32_t e
 #include PIV_VARIANT_FILE
 #else
 #include "zxc_pivco.inc"
+#include "zxc_pivco_dir.inc"
 #endif
 #include "zxc_rapidhash.inc"
 
@@ -1139,7 +1140,7 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
             if (enc_lit == 3u && !dict_huf) return E_DICT_REQUIRED;  // shared table comes with the dictionary
             if (S.n_lit > block_size) return E_CORRUPT;
             uint8_t* scratch = scratch_acquire(pool, lane) + 16;  // (the executor reads up to 3 bytes below a literal run)
-            const int rc = pivco_decode(pdata, lit_comp, scratch, S.n_lit, scratch + block_size + 48u,
+            const int rc = pivco_decode(pdata, lit_comp, scratch, S.n_lit, scratch + ZXC_DEV_SLOT_REGION(block_size) - 16u,
                                   reinterpret_cast<PivLds&>(L), lane, enc_lit == 3u ? dict_huf : nullptr, dbg);
             if (rc != 0) return rc;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1167,8 +1168,8 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
     if (enc_tok == 2u) {  // level 7: the token bytes are a PivCo section too
         if (S.n_seq > block_size / 5u + 16u) return E_CORRUPT;
         uint8_t* scratch = scratch_acquire(pool, lane);
-        uint8_t* tokbuf = scratch + 2u * (block_size + 64u);
-        const int rc = pivco_decode(S.tok, tok_comp, tokbuf, S.n_seq, scratch + block_size + 64u,
+        uint8_t* tokbuf = scratch + 2u * ZXC_DEV_SLOT_REGION(block_size);
+        const int rc = pivco_decode(S.tok, tok_comp, tokbuf, S.n_seq, scratch + ZXC_DEV_SLOT_REGION(block_size),
                                     reinterpret_cast<PivLds&>(L), lane, nullptr, dbg);
         if (rc != 0) return rc;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1329,6 +1330,38 @@ __device__ __forceinline__ bool block_needs_full_kernel(const uint8_t* __restric
     return ld8(src + 16) != 0u || ld8(src + 17) != 0u;
 }
 
+// The class of a block in a launch without a dictionary (zxc_dev.h). PRE = a GLO block whose coded sections are PivCo
+// (no RLE) and fit the workgroup decoder's LDS, with every header field the section kernel and the lean kernel rely on
+// already valid; anything else that needs the full kernel — malformed headers included, it names their errors — is FULL.
+// need16: scratch for the decoded sections, in 16-byte units.
+__device__ __forceinline__ uint32_t classify_block(const uint8_t* __restrict__ src, uint32_t src_sz, uint32_t trailer_bytes,
+                                                   uint32_t block_size, uint32_t cap, uint32_t& lit16, uint32_t& tok16) {
+    lit16 = 0;
+    tok16 = 0;
+    if (!block_needs_full_kernel(src, src_sz, trailer_bytes)) return ZXC_DEV_CLS_LEAN;
+    const uint8_t* data = src + 8;
+    const uint32_t comp_sz = ld32(src + 3);
+    const uint32_t n_seq = ld32(data), n_lit = ld32(data + 4), enc_lit = ld8(data + 8), enc_tok = ld8(data + 9), enc_off = ld8(data + 11);
+    if ((enc_lit != 0u && enc_lit != 2u) || (enc_tok != 0u && enc_tok != 2u) || enc_off > 1u) return ZXC_DEV_CLS_FULL;
+    const uint32_t desc = (enc_lit != 0u ? 4u : 0u) + (enc_tok == 2u ? 4u : 0u);
+    if (comp_sz < 12u + desc) return ZXC_DEV_CLS_FULL;
+    uint32_t lit_comp = n_lit, tok_comp = n_seq;
+    const uint8_t* d = data + 12;
+    if (enc_lit != 0u) { lit_comp = ld32(d); d += 4; }
+    if (enc_tok == 2u) { tok_comp = ld32(d); d += 4; }
+    const uint32_t avail = comp_sz - 12u - desc;
+    if (lit_comp > avail) return ZXC_DEV_CLS_FULL;
+    if (enc_lit == 2u && (n_lit == 0u || n_lit > cap || n_lit > block_size || n_lit > PDIR_N_MAX || lit_comp < 128u || lit_comp - 128u > PDIR_BODY_MAX))
+        return ZXC_DEV_CLS_FULL;
+    const uint64_t consumed = (uint64_t)lit_comp + tok_comp + (uint64_t)n_seq * (enc_off ? 1u : 2u);
+    if (consumed > avail || avail - lit_comp < 32u) return ZXC_DEV_CLS_FULL;
+    if (enc_tok == 2u && (n_seq == 0u || n_seq > block_size / 5u + 16u || n_seq > PDIR_N_MAX || tok_comp < 128u || tok_comp - 128u > PDIR_BODY_MAX))
+        return ZXC_DEV_CLS_FULL;
+    if (enc_lit == 2u) lit16 = (16u + n_lit + 64u + 15u) >> 4;  // 16 bytes in front (the executor reads up to 3 bytes below a literal run), 64 behind
+    if (enc_tok == 2u) tok16 = (n_seq + 64u + 15u) >> 4;
+    return ZXC_DEV_CLS_PRE;
+}
+
 // ------------------------------------------------------------------ the lean kernel
 // One wavefront per block like the full kernel, built for LEAN_WAVES_PER_SIMD waves per SIMD (<= 64 VGPRs, < 5 KiB LDS):
 // RAW blocks and GLO / GHI blocks with raw sections, no checksum, no dictionary. A block it cannot take is appended to
@@ -1336,7 +1369,8 @@ __device__ __forceinline__ bool block_needs_full_kernel(const uint8_t* __restric
 extern "C" __global__ void __launch_bounds__(64, LEAN_WAVES_PER_SIMD)
 zxc_decode_blocks_lean_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
                               uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,
-                              const uint32_t* __restrict__ order, uint32_t cap_override, uint32_t trailer_bytes) {
+                              const uint32_t* __restrict__ order, uint32_t cap_override, uint32_t trailer_bytes,
+                              const zxc_dev_pre_t* __restrict__ pre, const uint8_t* __restrict__ pscratch) {
     __shared__ LeanLds L;
     const int lane = threadIdx.x;
     if (blockIdx.x >= n_jobs) return;
@@ -1348,7 +1382,8 @@ zxc_decode_blocks_lean_kernel(const uint8_t* __restrict__ comp, const zxc_dev_jo
     const uint8_t* src = comp + comp_off;
     uint8_t* dst = out + jobs[b].out_off;
     int rc;
-    if (uni(block_needs_full_kernel(src, src_sz, trailer_bytes) ? 1u : 0u)) return;  // on the full kernel's list (zxc_order_scatter_kernel)
+    const uint32_t cls = uni(pre[b].cls);  // (zxc_order_scatter_kernel)
+    if (cls == ZXC_DEV_CLS_FULL) return;  // on the full kernel's list
     if (src_sz < 8u) {
         rc = E_SRC_TOO_SMALL;
     } else {
@@ -1359,7 +1394,8 @@ zxc_decode_blocks_lean_kernel(const uint8_t* __restrict__ comp, const zxc_dev_jo
         } else if (trailer_bytes && wave_checksum32(src + 8, comp_sz, lane) != uni(ld32(src + 8 + comp_sz))) {
             rc = E_BAD_CHECKSUM;  // per-block checksum of the compressed payload (zxc_decompress.c:1662-1666)
         } else if (type == 1u || type == 2u) {
-            rc = decode_lz_block_lean(src + 8, comp_sz, type == 2u, dst, out_len, cap, L, lane);
+            rc = decode_lz_block_lean(src + 8, comp_sz, type == 2u, dst, out_len, cap, L, lane, cls == ZXC_DEV_CLS_PRE ? pre + b : nullptr,
+                                      pscratch);
         } else if (type == 0u) {  // RAW: stored bytes
             if (comp_sz > cap) rc = E_DST_TOO_SMALL;
             else {
@@ -1422,7 +1458,8 @@ zxc_order_hist_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __r
 extern "C" __global__ void __launch_bounds__(256)
 zxc_order_scatter_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
                          uint32_t block_size, uint32_t* __restrict__ hist, uint32_t* __restrict__ order,
-                         uint32_t* __restrict__ list, uint32_t trailer_bytes) {
+                         uint32_t* __restrict__ list, uint32_t trailer_bytes, zxc_dev_pre_t* __restrict__ pre,
+                         uint32_t* __restrict__ plist, uint32_t pscratch_cap16, uint32_t cap) {
     __shared__ uint32_t cnt[64], base[64];
     if (threadIdx.x < 64u) cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -1441,7 +1478,22 @@ zxc_order_scatter_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* 
     __syncthreads();
     if (i < n_jobs) {
         order[base[bk] + rank] = i;
-        // two-pass launches: positions (in launch order) of the blocks the full kernel decodes; list[0] = their number, list[1] = 0
-        if (list && block_needs_full_kernel(comp + jobs[i].comp_off, jobs[i].comp_size, trailer_bytes)) list[2u + atomicAdd(list, 1u)] = base[bk] + rank;
+        // two-pass launches: the block's class. FULL: its position (in launch order) goes on the full kernel's list (list[0] =
+        // entries, list[1] = 0); PRE: scratch for its decoded sections from the cursor plist[2], the job on the section kernel's list.
+        if (list) {
+            uint32_t lit16, tok16;
+            uint32_t cls = classify_block(comp + jobs[i].comp_off, jobs[i].comp_size, trailer_bytes, block_size, cap, lit16, tok16);
+            uint32_t off = 0;
+            if (cls == ZXC_DEV_CLS_PRE) {
+                off = atomicAdd(plist + 2, lit16 + tok16);
+                if ((uint64_t)off + lit16 + tok16 > pscratch_cap16) cls = ZXC_DEV_CLS_FULL;  // (scratch exhausted: the one-wave decoder has its own slots)
+            }
+            pre[i].lit_off = off;
+            pre[i].tok_off = off + lit16;
+            pre[i].rc = 0;
+            pre[i].cls = cls;
+            if (cls == ZXC_DEV_CLS_FULL) list[2u + atomicAdd(list, 1u)] = base[bk] + rank;
+            else if (cls == ZXC_DEV_CLS_PRE) plist[4u + atomicAdd(plist, 1u)] = i;
+        }
     }
 }

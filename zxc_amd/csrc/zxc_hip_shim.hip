@@ -16,11 +16,15 @@ extern "C" __global__ void zxc_decode_blocks_kernel(const uint8_t* comp, const z
                                                     uint32_t cap_override, uint32_t* list);
 extern "C" __global__ void zxc_decode_blocks_lean_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                          uint8_t* out, int32_t* status, uint32_t block_size,
-                                                         const uint32_t* order, uint32_t cap_override, uint32_t trailer_bytes);
+                                                         const uint32_t* order, uint32_t cap_override, uint32_t trailer_bytes,
+                                                         const zxc_dev_pre_t* pre, const uint8_t* pscratch);
+extern "C" __global__ void zxc_pivco_sections_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, zxc_dev_pre_t* pre, uint32_t* plist,
+                                                     uint8_t* pscratch);
 extern "C" __global__ void zxc_order_hist_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                  uint32_t block_size, uint32_t* hist);
 extern "C" __global__ void zxc_order_scatter_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
-                                                    uint32_t block_size, uint32_t* hist, uint32_t* order, uint32_t* list, uint32_t trailer_bytes);
+                                                    uint32_t block_size, uint32_t* hist, uint32_t* order, uint32_t* list, uint32_t trailer_bytes,
+                                                    zxc_dev_pre_t* pre, uint32_t* plist, uint32_t pscratch_cap16, uint32_t cap);
 extern "C" __global__ void zxc_decode_blocks_dict_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                          uint8_t* out, int32_t* status, uint32_t block_size,
                                                          uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride,
@@ -57,7 +61,7 @@ static struct {
     int wg_per_cu;
     /* launch-order buffers ([128 u32 histogram + cursors | order[n]]), one per stream seen: launches on
      * one stream are ordered, so a stream's buffer is free again when its next launch is enqueued */
-    struct { void* stream; uint32_t* buf; size_t cap; int used; hipStream_t aux; hipEvent_t fork, join; } ord[ZXC_ORDER_STREAMS];
+    struct { void* stream; uint32_t* buf; size_t cap; int used; hipStream_t aux; hipEvent_t fork, join; uint8_t* pscratch; size_t pscratch_cap; } ord[ZXC_ORDER_STREAMS];
 } g_dev[ZXC_MAX_DEVICES];
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 
@@ -161,7 +165,9 @@ void zxc_mi355x_release_cached(void) {
     for (int i = 0; i < ZXC_ORDER_STREAMS; i++) {
         auto& o = g_dev[dev].ord[i];
         if (o.buf) (void)hipFree(o.buf);
+        if (o.pscratch) (void)hipFree(o.pscratch);
         o.buf = NULL; o.cap = 0;
+        o.pscratch = NULL; o.pscratch_cap = 0;
     }
     pthread_mutex_unlock(&g_lock);
 }
@@ -194,7 +200,7 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
         g_dev[dev].wg_per_cu = nb;
     }
     // scratch slot: [expanded literals | PivCo ping-pong | decoded tokens]
-    const uint32_t stride = (2u * (block_size + 64u) + block_size / 5u + 16u + 64u + 255u) & ~255u;
+    const uint32_t stride = ZXC_DEV_SLOT_STRIDE(block_size);
     // Only blocks with an RLE / PivCo section take a slot, waiters spin and holders never wait, so
     // the pool may be smaller than the resident workgroup count: cap it at 1 GiB of scratch.
     const uint32_t max_slots = (uint32_t)g_dev[dev].cus * (uint32_t)g_dev[dev].wg_per_cu;  // <= 8192
@@ -230,6 +236,10 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
     const bool want_order = two_pass || (n_jobs > max_slots && !(g_debug_flags & 0x80000000u));
     uint32_t* order = NULL;
     uint32_t* list = NULL;
+    uint32_t* plist = NULL;  // the workgroup section decoder's list, the per-block class records and its scratch
+    zxc_dev_pre_t* pre = NULL;
+    uint8_t* pscratch = NULL;
+    uint32_t pscratch_cap16 = 0;
     int k = -1;
     if (want_order) {
         for (int i = 0; i < ZXC_ORDER_STREAMS; i++)
@@ -238,7 +248,8 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
             if (!g_dev[dev].ord[i].used) { k = i; g_dev[dev].ord[i].used = 1; g_dev[dev].ord[i].stream = stream; }
         if (k >= 0) {  // (more distinct streams than buffers: one kernel in plain order, still correct)
             auto& o = g_dev[dev].ord[k];
-            const size_t want = 130u + 2u * (size_t)n_jobs;
+            const size_t pre_at = (134u + 3u * (size_t)n_jobs + 3u) & ~(size_t)3u;  // (16-byte records)
+            const size_t want = pre_at + 4u * (size_t)n_jobs;
             if (o.cap < want) {
                 if (o.buf) (void)hipFree(o.buf);
                 o.buf = NULL;
@@ -253,14 +264,37 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
                     o.aux = NULL;
                 }
             }
+            // scratch for the sections the workgroup decoder expands ahead of the lean kernel (levels 6-7): what this launch can
+            // need at most, capped at 1 GiB (blocks beyond it go to the full kernel and its slot pool); grows, never shrinks
+            if (two_pass && o.aux) {
+                size_t need = (size_t)n_jobs * ((size_t)block_size + block_size / 5u + 256u);
+                if (need > ((size_t)1 << 30)) need = (size_t)1 << 30;
+                if (o.pscratch_cap < need) {
+                    if (o.pscratch) (void)hipFree(o.pscratch);
+                    o.pscratch = NULL;
+                    o.pscratch_cap = 0;
+                    if (hipMalloc((void**)&o.pscratch, need) == hipSuccess) o.pscratch_cap = need;
+                }
+            }
             uint32_t* buf = o.buf;
-            if (buf && hipMemsetAsync(buf, 0, 130u * 4u, (hipStream_t)stream) == hipSuccess) {
-                if (two_pass && o.aux) list = buf + 128;
+            if (buf && hipMemsetAsync(buf, 0, 130u * 4u, (hipStream_t)stream) == hipSuccess &&
+                hipMemsetAsync(buf + 130 + 2u * (size_t)n_jobs, 0, 4u * 4u, (hipStream_t)stream) == hipSuccess) {
+                if (two_pass && o.aux) {
+                    list = buf + 128;
+                    plist = buf + 130 + 2u * (size_t)n_jobs;
+                    pre = (zxc_dev_pre_t*)(buf + pre_at);
+                    pscratch = o.pscratch;
+                    pscratch_cap16 = (uint32_t)(o.pscratch_cap >> 4);
+#ifdef EXP_NO_PRE  // (experiment: every coded block to the full kernel; the section kernel runs over an empty list)
+                    pscratch_cap16 = 0;
+#endif
+                }
                 const uint32_t g = (n_jobs + 255u) / 256u;
                 hipLaunchKernelGGL(zxc_order_hist_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
                                    d_jobs, n_jobs, block_size, buf);
                 hipLaunchKernelGGL(zxc_order_scatter_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream,
-                                   (const uint8_t*)d_comp, d_jobs, n_jobs, block_size, buf, buf + 130 + n_jobs, list, verify_trailer ? 4u : 0u);
+                                   (const uint8_t*)d_comp, d_jobs, n_jobs, block_size, buf, buf + 130 + n_jobs, list, verify_trailer ? 4u : 0u,
+                                   pre, plist, pscratch_cap16, cap_override ? cap_override : block_size + 2112u);
                 order = buf + 130 + n_jobs;
             }
         }
@@ -282,8 +316,16 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
                            cap_override, list);
         if (forked && hipEventRecord(o.join, o.aux) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
 #endif
+        // coded sections of the PRE blocks first (a fixed grid pulls them; an empty list costs one idle launch), then every
+        // block that is not on the full kernel's list
+        {
+            const uint32_t wgs = 2u * (uint32_t)g_dev[dev].cus;
+            hipLaunchKernelGGL(zxc_pivco_sections_kernel, dim3(n_jobs < wgs ? n_jobs : wgs), dim3(512), 0, (hipStream_t)stream,
+                               (const uint8_t*)d_comp, d_jobs, pre, plist, pscratch);
+        }
         hipLaunchKernelGGL(zxc_decode_blocks_lean_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
-                           d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, order, cap_override, verify_trailer ? 4u : 0u);
+                           d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, order, cap_override, verify_trailer ? 4u : 0u,
+                           (const zxc_dev_pre_t*)pre, (const uint8_t*)pscratch);
         if (forked && hipStreamWaitEvent((hipStream_t)stream, o.join, 0) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
     } else
         hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
