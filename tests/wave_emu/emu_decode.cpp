@@ -40,42 +40,37 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
             }, b, n_jobs, 64);
         }
     } else {
-        // the two-pass launch of zxc_hip_shim.hip: the lean kernel over every block (in a launch order that is not the
-        // identity), then the full kernel, a fixed grid walking the list of blocks the lean kernel handed over
-        std::vector<uint32_t> order(n_jobs), list(n_jobs + 2u, 0u), plist(n_jobs + 4u, 0u);
+        // the two-pass launch of zxc_hip_shim.hip, kernel by kernel: launch-order pass (histogram + scatter: order[], classes, work
+        // lists), the section kernels of the three size classes, the lean kernel over every block, its second entry over the PRE
+        // blocks, the full kernel over its list
+        const uint32_t tb = verify_trailer ? 4u : 0u, g256 = (n_jobs + 255u) / 256u;
+        std::vector<uint32_t> hist(128, 0u), order(n_jobs), list(n_jobs + 2u, 0u), ctl(ZXC_DEV_CTL_WORDS, 0u), pre_entries(n_jobs);
         std::vector<zxc_dev_pre_t> pre(n_jobs);
+        std::vector<zxc_dev_sec_t> secs(6u * (size_t)n_jobs);
         std::vector<uint8_t> pscratch(emu_pscratch_bytes + 4096, 0xC3);
-        for (uint32_t b = 0; b < n_jobs; b++) {
-            order[b] = n_jobs - 1u - b;
-            // (what zxc_order_scatter_kernel records and appends, by the same predicate)
-            const uint32_t i = order[b];
-            uint32_t lit16, tok16, off = 0;
-            uint32_t cls = classify_block(c.data() + 4096 + jobs[i].comp_off, jobs[i].comp_size, verify_trailer ? 4u : 0u, block_size,
-                                          block_size + 2112u, lit16, tok16);
-            if (cls == ZXC_DEV_CLS_PRE) {
-                off = plist[2];
-                plist[2] += lit16 + tok16;
-                if ((uint64_t)off + lit16 + tok16 > (emu_pscratch_bytes >> 4)) cls = ZXC_DEV_CLS_FULL;
+        auto launch = [&](unsigned grid, int threads, const std::function<void()>& k) {
+            for (unsigned g = 0; g < grid; g++) {
+                memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));  // LDS is not zero at launch
+                emu::run_wave(k, g, grid, threads);
             }
-            pre[i] = zxc_dev_pre_t{off, off + lit16, 0, cls};
-            if (cls == ZXC_DEV_CLS_FULL) list[2u + list[0]++] = b;
-            else if (cls == ZXC_DEV_CLS_PRE) plist[4u + plist[0]++] = i;
-        }
-        emu_last_pre = plist[0];
-        if (plist[0]) {  // the workgroup section decoder: 512 threads = 8 emulated wavefronts sharing LDS
-            const uint32_t wgs = plist[0] < 2u ? plist[0] : 2u;
-            for (uint32_t g = 0; g < wgs; g++) {
-                memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));
-                emu::run_wave([&] { zxc_pivco_sections_kernel(c.data() + 4096, jobs, pre.data(), plist.data(), pscratch.data()); }, g, wgs, 512);
-            }
-        }
-        for (uint32_t b = 0; b < n_jobs; b++) {
-            memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));
-            emu::run_wave([&] {
-                zxc_decode_blocks_lean_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, order.data(), 0u, verify_trailer ? 4u : 0u,
-                                              pre.data(), pscratch.data());
-            }, b, n_jobs, 64);
-        }
+        };
+        launch(g256, 256, [&] { zxc_order_hist_kernel(c.data() + 4096, jobs, n_jobs, block_size, hist.data()); });
+        launch(g256, 256, [&] {
+            zxc_order_scatter_kernel(c.data() + 4096, jobs, n_jobs, block_size, hist.data(), order.data(), list.data(), tb, pre.data(), ctl.data(),
+                                     pre_entries.data(), secs.data(), (uint32_t)(emu_pscratch_bytes >> 4), block_size + 2112u);
+        });
+        emu_last_pre = ctl[ZXC_DEV_CTL_PRE];
+        uint32_t* sec_hdr = ctl.data() + ZXC_DEV_CTL_SEC;
+        if (sec_hdr[0]) launch(2, 128, [&] { zxc_pivco_sections_small_kernel(c.data() + 4096, secs.data(), sec_hdr, pre.data(), pscratch.data()); });
+        if (sec_hdr[2]) launch(2, 256, [&] { zxc_pivco_sections_medium_kernel(c.data() + 4096, secs.data() + 2u * (size_t)n_jobs, sec_hdr + 2, pre.data(), pscratch.data()); });
+        if (sec_hdr[4]) launch(2, 512, [&] { zxc_pivco_sections_large_kernel(c.data() + 4096, secs.data() + 4u * (size_t)n_jobs, sec_hdr + 4, pre.data(), pscratch.data()); });
+        launch(n_jobs, 64, [&] {
+            zxc_decode_blocks_lean_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, order.data(), 0u, tb, pre.data());
+        });
+        if (ctl[ZXC_DEV_CTL_PRE]) launch(n_jobs, 64, [&] {
+            zxc_decode_blocks_lean_pre_kernel(c.data() + 4096, jobs, o.data() + 4096, status, block_size, 0u, tb, pre.data(), pscratch.data(),
+                                              ctl.data() + ZXC_DEV_CTL_PRE, pre_entries.data());
+        });
         emu_last_deferred = list[0];
         const uint32_t grid = n_jobs < 3u ? n_jobs : 3u;
         for (uint32_t b = 0; b < grid; b++) {

@@ -80,6 +80,9 @@ inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, b
 inline uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * (sh & 3u)));
 }
+inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {  // v_alignbit_b32
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u));
+}
 inline uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel) {  // v_perm_b32
     const uint64_t src = ((uint64_t)s0 << 32) | s1;
     uint32_t r = 0;
@@ -130,6 +133,7 @@ template <typename T> inline T ntload(const void* p) { T v; memcpy(&v, p, sizeof
 #define __builtin_amdgcn_mov_dpp(s, c, rm, bm, bc) emu::update_dpp(0, (s), (c), (rm), (bm), (bc), __LINE__)
 #define __builtin_amdgcn_alignbyte(h, l, s) emu::alignbyte((h), (l), (s))
 #define __builtin_amdgcn_perm(a, b, s) emu::perm((a), (b), (s))
+#define __builtin_amdgcn_alignbit(h, l, s) emu::alignbit((h), (l), (s))
 #define __builtin_amdgcn_mbcnt_lo(m, a) emu::mbcnt((m), (a), false)
 #define __builtin_amdgcn_mbcnt_hi(m, a) emu::mbcnt((m), (a), true)
 #define __builtin_amdgcn_ds_bpermute(addr, v) ((int)emu::shfl((uint32_t)(v), (int)((addr) >> 2), __LINE__))

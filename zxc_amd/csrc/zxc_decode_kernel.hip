@@ -1331,50 +1331,66 @@ __device__ __forceinline__ bool block_needs_full_kernel(const uint8_t* __restric
 }
 
 // The class of a block in a launch without a dictionary (zxc_dev.h). PRE = a GLO block whose coded sections are PivCo
-// (no RLE) and fit the workgroup decoder's LDS, with every header field the section kernel and the lean kernel rely on
+// (no RLE) and fit a workgroup decoder's LDS, with every header field the section kernels and the lean kernel rely on
 // already valid; anything else that needs the full kernel — malformed headers included, it names their errors — is FULL.
-// need16: scratch for the decoded sections, in 16-byte units.
-__device__ __forceinline__ uint32_t classify_block(const uint8_t* __restrict__ src, uint32_t src_sz, uint32_t trailer_bytes,
-                                                   uint32_t block_size, uint32_t cap, uint32_t& lit16, uint32_t& tok16) {
-    lit16 = 0;
-    tok16 = 0;
-    if (!block_needs_full_kernel(src, src_sz, trailer_bytes)) return ZXC_DEV_CLS_LEAN;
+struct BlockClass {
+    uint32_t cls;
+    uint32_t lit16, tok16;      // scratch for the decoded sections, 16-byte units
+    uint32_t lit_cls, tok_cls;  // size class of the section's work list (pdir_class), 3 = not coded
+    uint32_t lit_at, lit_psize, n_lit, tok_at, tok_psize, n_seq;  // payload offsets from the block's first byte, sizes, symbols
+};
+__device__ __forceinline__ BlockClass classify_block(const uint8_t* __restrict__ src, uint32_t src_sz, uint32_t trailer_bytes,
+                                                     uint32_t block_size, uint32_t cap) {
+    BlockClass r = {ZXC_DEV_CLS_LEAN, 0, 0, 3, 3, 0, 0, 0, 0, 0, 0};
+    if (!block_needs_full_kernel(src, src_sz, trailer_bytes)) return r;
+    r.cls = ZXC_DEV_CLS_FULL;
     const uint8_t* data = src + 8;
     const uint32_t comp_sz = ld32(src + 3);
     const uint32_t n_seq = ld32(data), n_lit = ld32(data + 4), enc_lit = ld8(data + 8), enc_tok = ld8(data + 9), enc_off = ld8(data + 11);
-    if ((enc_lit != 0u && enc_lit != 2u) || (enc_tok != 0u && enc_tok != 2u) || enc_off > 1u) return ZXC_DEV_CLS_FULL;
+    if ((enc_lit != 0u && enc_lit != 2u) || (enc_tok != 0u && enc_tok != 2u) || enc_off > 1u) return r;
     const uint32_t desc = (enc_lit != 0u ? 4u : 0u) + (enc_tok == 2u ? 4u : 0u);
-    if (comp_sz < 12u + desc) return ZXC_DEV_CLS_FULL;
+    if (comp_sz < 12u + desc) return r;
     uint32_t lit_comp = n_lit, tok_comp = n_seq;
     const uint8_t* d = data + 12;
     if (enc_lit != 0u) { lit_comp = ld32(d); d += 4; }
     if (enc_tok == 2u) { tok_comp = ld32(d); d += 4; }
     const uint32_t avail = comp_sz - 12u - desc;
-    if (lit_comp > avail) return ZXC_DEV_CLS_FULL;
-    if (enc_lit == 2u && (n_lit == 0u || n_lit > cap || n_lit > block_size || n_lit > PDIR_N_MAX || lit_comp < 128u || lit_comp - 128u > PDIR_BODY_MAX))
-        return ZXC_DEV_CLS_FULL;
+    if (lit_comp > avail) return r;
+    if (enc_lit == 2u && (n_lit == 0u || n_lit > cap || n_lit > block_size || n_lit > PDIR_N_MAX || lit_comp < 128u || pdir_class(lit_comp - 128u) > 2u))
+        return r;
     const uint64_t consumed = (uint64_t)lit_comp + tok_comp + (uint64_t)n_seq * (enc_off ? 1u : 2u);
-    if (consumed > avail || avail - lit_comp < 32u) return ZXC_DEV_CLS_FULL;
-    if (enc_tok == 2u && (n_seq == 0u || n_seq > block_size / 5u + 16u || n_seq > PDIR_N_MAX || tok_comp < 128u || tok_comp - 128u > PDIR_BODY_MAX))
-        return ZXC_DEV_CLS_FULL;
-    if (enc_lit == 2u) lit16 = (16u + n_lit + 64u + 15u) >> 4;  // 16 bytes in front (the executor reads up to 3 bytes below a literal run), 64 behind
-    if (enc_tok == 2u) tok16 = (n_seq + 64u + 15u) >> 4;
-    return ZXC_DEV_CLS_PRE;
+    if (consumed > avail || avail - lit_comp < 32u) return r;
+    if (enc_tok == 2u && (n_seq == 0u || n_seq > block_size / 5u + 16u || n_seq > PDIR_N_MAX || tok_comp < 128u || pdir_class(tok_comp - 128u) > 2u))
+        return r;
+    r.cls = ZXC_DEV_CLS_PRE;
+    if (enc_lit == 2u) {
+        r.lit16 = (16u + n_lit + 64u + 15u) >> 4;  // 16 bytes in front (the executor reads up to 3 bytes below a literal run), 64 behind
+        r.lit_cls = pdir_class(lit_comp - 128u);
+        r.lit_at = 8u + 12u + desc;
+        r.lit_psize = lit_comp;
+        r.n_lit = n_lit;
+    }
+    if (enc_tok == 2u) {
+        r.tok16 = (n_seq + 64u + 15u) >> 4;
+        r.tok_cls = pdir_class(tok_comp - 128u);
+        r.tok_at = 8u + 12u + desc + lit_comp;
+        r.tok_psize = tok_comp;
+        r.n_seq = n_seq;
+    }
+    return r;
 }
 
 // ------------------------------------------------------------------ the lean kernel
 // One wavefront per block like the full kernel, built for LEAN_WAVES_PER_SIMD waves per SIMD (<= 64 VGPRs, < 5 KiB LDS):
-// RAW blocks and GLO / GHI blocks with raw sections, no checksum, no dictionary. A block it cannot take is appended to
-// `list` for the full kernel (see above) and its status slot is left alone.
-extern "C" __global__ void __launch_bounds__(64, LEAN_WAVES_PER_SIMD)
-zxc_decode_blocks_lean_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
-                              uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,
-                              const uint32_t* __restrict__ order, uint32_t cap_override, uint32_t trailer_bytes,
-                              const zxc_dev_pre_t* __restrict__ pre, const uint8_t* __restrict__ pscratch) {
-    __shared__ LeanLds L;
-    const int lane = threadIdx.x;
-    if (blockIdx.x >= n_jobs) return;
-    const uint32_t b = order ? uni(order[blockIdx.x]) : blockIdx.x;
+// RAW blocks and GLO / GHI blocks with raw sections, no checksum, no dictionary. Two entries share this body. The first
+// runs over every block of the launch and takes the LEAN class (zxc_dev.h); the second pulls the PRE blocks from their list
+// once the section kernels have decoded their coded sections into pscratch (PRE = true).
+template <bool PRE>
+__device__ __forceinline__ void lean_one_block(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs,
+                                               uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,
+                                               uint32_t cap_override, uint32_t trailer_bytes, uint32_t b,
+                                               const zxc_dev_pre_t* __restrict__ pre, const uint8_t* __restrict__ pscratch, LeanLds& L,
+                                               int lane) {
     const uint32_t cap = cap_override ? cap_override : block_size + 2112u;
     const uint64_t comp_off = jobs[b].comp_off;
     const uint32_t src_sz = uni(jobs[b].comp_size);
@@ -1382,8 +1398,6 @@ zxc_decode_blocks_lean_kernel(const uint8_t* __restrict__ comp, const zxc_dev_jo
     const uint8_t* src = comp + comp_off;
     uint8_t* dst = out + jobs[b].out_off;
     int rc;
-    const uint32_t cls = uni(pre[b].cls);  // (zxc_order_scatter_kernel)
-    if (cls == ZXC_DEV_CLS_FULL) return;  // on the full kernel's list
     if (src_sz < 8u) {
         rc = E_SRC_TOO_SMALL;
     } else {
@@ -1393,9 +1407,10 @@ zxc_decode_blocks_lean_kernel(const uint8_t* __restrict__ comp, const zxc_dev_jo
             rc = E_SRC_TOO_SMALL;
         } else if (trailer_bytes && wave_checksum32(src + 8, comp_sz, lane) != uni(ld32(src + 8 + comp_sz))) {
             rc = E_BAD_CHECKSUM;  // per-block checksum of the compressed payload (zxc_decompress.c:1662-1666)
+        } else if (PRE) {  // (a GLO block, by classify_block: nothing else is compiled into the second entry)
+            rc = type == 1u ? decode_lz_block_lean(src + 8, comp_sz, false, dst, out_len, cap, L, lane, pre + b, pscratch) : ZXC_DEV_E_INTERNAL;
         } else if (type == 1u || type == 2u) {
-            rc = decode_lz_block_lean(src + 8, comp_sz, type == 2u, dst, out_len, cap, L, lane, cls == ZXC_DEV_CLS_PRE ? pre + b : nullptr,
-                                      pscratch);
+            rc = decode_lz_block_lean(src + 8, comp_sz, type == 2u, dst, out_len, cap, L, lane, nullptr, pscratch);
         } else if (type == 0u) {  // RAW: stored bytes
             if (comp_sz > cap) rc = E_DST_TOO_SMALL;
             else {
@@ -1421,7 +1436,31 @@ zxc_decode_blocks_lean_kernel(const uint8_t* __restrict__ comp, const zxc_dev_jo
             rc = E_BAD_BLOCK_TYPE;
         }
     }
-    if (lane == 0) status[b] = rc == ZXC_DEV_DEFER ? ZXC_DEV_E_INTERNAL : rc;  // (DEFER cannot happen: see the predicate)
+    if (lane == 0) status[b] = rc == ZXC_DEV_DEFER ? ZXC_DEV_E_INTERNAL : rc;  // (DEFER cannot happen: see classify_block)
+}
+
+extern "C" __global__ void __launch_bounds__(64, LEAN_WAVES_PER_SIMD)
+zxc_decode_blocks_lean_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
+                              uint8_t* __restrict__ out, int32_t* __restrict__ status, uint32_t block_size,
+                              const uint32_t* __restrict__ order, uint32_t cap_override, uint32_t trailer_bytes,
+                              const zxc_dev_pre_t* __restrict__ pre) {
+    __shared__ LeanLds L;
+    if (blockIdx.x >= n_jobs) return;
+    const uint32_t b = order ? uni(order[blockIdx.x]) : blockIdx.x;
+    if (uni(pre[b].cls) != ZXC_DEV_CLS_LEAN) return;  // on the full kernel's list, or on the second entry's (zxc_order_scatter_kernel)
+    lean_one_block<false>(comp, jobs, out, status, block_size, cap_override, trailer_bytes, b, nullptr, nullptr, L, threadIdx.x);
+}
+
+// hdr[0] = PRE blocks listed, entries = their job indices; launched with one workgroup per block of the launch, the ones beyond
+// the list leave at once (a fixed grid pulling entries in a loop kept 26 VGPRs of loop state in scratch memory: -20 %).
+extern "C" __global__ void __launch_bounds__(64, LEAN_WAVES_PER_SIMD)
+zxc_decode_blocks_lean_pre_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint8_t* __restrict__ out,
+                                  int32_t* __restrict__ status, uint32_t block_size, uint32_t cap_override, uint32_t trailer_bytes,
+                                  const zxc_dev_pre_t* __restrict__ pre, const uint8_t* __restrict__ pscratch,
+                                  const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ entries) {
+    __shared__ LeanLds L;
+    if (blockIdx.x >= uni(hdr[0])) return;
+    lean_one_block<true>(comp, jobs, out, status, block_size, cap_override, trailer_bytes, uni(entries[blockIdx.x]), pre, pscratch, L, threadIdx.x);
 }
 
 // ------------------------------------------------------------------ launch order
@@ -1455,13 +1494,20 @@ zxc_order_hist_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __r
     if (threadIdx.x < 64u && cnt[threadIdx.x]) atomicAdd(hist + threadIdx.x, cnt[threadIdx.x]);
 }
 
+// Work lists of a two-pass launch (list != nullptr), filled here from the block headers: the full kernel's (list[0] = entries,
+// list[1] = 0, positions in launch order from list[2]); behind order[]: ctl (zxc_dev.h), the PRE blocks' job indices, one array
+// of section records per size class (2 n each) and pre[]. Counters are bumped once per workgroup, not per block.
 extern "C" __global__ void __launch_bounds__(256)
 zxc_order_scatter_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
                          uint32_t block_size, uint32_t* __restrict__ hist, uint32_t* __restrict__ order,
                          uint32_t* __restrict__ list, uint32_t trailer_bytes, zxc_dev_pre_t* __restrict__ pre,
-                         uint32_t* __restrict__ plist, uint32_t pscratch_cap16, uint32_t cap) {
+                         uint32_t* __restrict__ ctl, uint32_t* __restrict__ pre_entries, zxc_dev_sec_t* __restrict__ secs,
+                         uint32_t pscratch_cap16, uint32_t cap) {
     __shared__ uint32_t cnt[64], base[64];
+    __shared__ uint32_t wg_cnt[6], wg_base[6];  // 0: scratch units, 1: PRE blocks, 2: FULL blocks, 3..5: sections per size class
+    __shared__ uint32_t wg_fit;
     if (threadIdx.x < 64u) cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 6u) wg_cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     uint32_t bk = 0, rank = 0;
@@ -1476,24 +1522,71 @@ zxc_order_scatter_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* 
         base[threadIdx.x] = cnt[threadIdx.x] ? s + atomicAdd(hist + 64u + threadIdx.x, cnt[threadIdx.x]) : 0u;
     }
     __syncthreads();
+    if (i < n_jobs) order[base[bk] + rank] = i;
+    if (!list) return;
+    BlockClass c = {ZXC_DEV_CLS_LEAN, 0, 0, 3, 3, 0, 0, 0, 0, 0, 0};
+    uint32_t my_off = 0, my_pre = 0, my_full = 0, my_lit = 0, my_tok = 0;
     if (i < n_jobs) {
-        order[base[bk] + rank] = i;
-        // two-pass launches: the block's class. FULL: its position (in launch order) goes on the full kernel's list (list[0] =
-        // entries, list[1] = 0); PRE: scratch for its decoded sections from the cursor plist[2], the job on the section kernel's list.
-        if (list) {
-            uint32_t lit16, tok16;
-            uint32_t cls = classify_block(comp + jobs[i].comp_off, jobs[i].comp_size, trailer_bytes, block_size, cap, lit16, tok16);
-            uint32_t off = 0;
-            if (cls == ZXC_DEV_CLS_PRE) {
-                off = atomicAdd(plist + 2, lit16 + tok16);
-                if ((uint64_t)off + lit16 + tok16 > pscratch_cap16) cls = ZXC_DEV_CLS_FULL;  // (scratch exhausted: the one-wave decoder has its own slots)
-            }
-            pre[i].lit_off = off;
-            pre[i].tok_off = off + lit16;
-            pre[i].rc = 0;
-            pre[i].cls = cls;
-            if (cls == ZXC_DEV_CLS_FULL) list[2u + atomicAdd(list, 1u)] = base[bk] + rank;
-            else if (cls == ZXC_DEV_CLS_PRE) plist[4u + atomicAdd(plist, 1u)] = i;
+        c = classify_block(comp + jobs[i].comp_off, jobs[i].comp_size, trailer_bytes, block_size, cap);
+        if (c.cls == ZXC_DEV_CLS_PRE) {
+            my_off = atomicAdd(wg_cnt + 0, c.lit16 + c.tok16);
+            my_pre = atomicAdd(wg_cnt + 1, 1u);
+            if (c.lit_cls < 3u) my_lit = atomicAdd(wg_cnt + 3u + c.lit_cls, 1u);
+            if (c.tok_cls < 3u) my_tok = atomicAdd(wg_cnt + 3u + c.tok_cls, 1u);
+        } else if (c.cls == ZXC_DEV_CLS_FULL) {
+            my_full = atomicAdd(wg_cnt + 2, 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bool fit = true;
+        wg_base[0] = 0;
+        if (wg_cnt[0]) {
+            wg_base[0] = atomicAdd(ctl + ZXC_DEV_CTL_CURSOR, wg_cnt[0]);
+            fit = (uint64_t)wg_base[0] + wg_cnt[0] <= pscratch_cap16;  // (scratch exhausted: this workgroup's PRE blocks go to the full kernel and its slot pool)
+        }
+        wg_fit = fit ? 1u : 0u;
+        if (wg_cnt[1]) atomicAdd(ctl + ZXC_DEV_CTL_WANTED, wg_cnt[1]);
+        if (fit) {
+            wg_base[1] = wg_cnt[1] ? atomicAdd(ctl + ZXC_DEV_CTL_PRE, wg_cnt[1]) : 0u;
+            wg_base[2] = wg_cnt[2] ? atomicAdd(list, wg_cnt[2]) : 0u;
+            for (uint32_t k = 0; k < 3u; k++) wg_base[3u + k] = wg_cnt[3u + k] ? atomicAdd(ctl + ZXC_DEV_CTL_SEC + 2u * k, wg_cnt[3u + k]) : 0u;
+        } else {
+            wg_base[2] = atomicAdd(list, wg_cnt[2] + wg_cnt[1]);
+        }
+    }
+    __syncthreads();
+    if (i >= n_jobs) return;
+    uint32_t cls = c.cls;
+    if (cls == ZXC_DEV_CLS_PRE && !wg_fit) {
+        cls = ZXC_DEV_CLS_FULL;
+        my_full = wg_cnt[2] + my_pre;
+    }
+    const uint32_t off = wg_base[0] + my_off;
+    pre[i].lit_off = off;
+    pre[i].tok_off = off + c.lit16;
+    pre[i].rc_lit = 0;
+    pre[i].rc_tok = 0;
+    pre[i].cls = cls;
+    if (cls == ZXC_DEV_CLS_FULL) {
+        list[2u + wg_base[2] + my_full] = base[bk] + rank;
+    } else if (cls == ZXC_DEV_CLS_PRE) {
+        pre_entries[wg_base[1] + my_pre] = i;
+        if (c.lit_cls < 3u) {
+            zxc_dev_sec_t& s = secs[(size_t)c.lit_cls * 2u * n_jobs + wg_base[3u + c.lit_cls] + my_lit];
+            s.src_off = jobs[i].comp_off + c.lit_at;
+            s.psize = c.lit_psize;
+            s.n = c.n_lit;
+            s.out_off4 = 4u * off + 4u;
+            s.rc_slot = 8u * i + 4u;
+        }
+        if (c.tok_cls < 3u) {
+            zxc_dev_sec_t& s = secs[(size_t)c.tok_cls * 2u * n_jobs + wg_base[3u + c.tok_cls] + my_tok];
+            s.src_off = jobs[i].comp_off + c.tok_at;
+            s.psize = c.tok_psize;
+            s.n = c.n_seq;
+            s.out_off4 = 4u * (off + c.lit16);
+            s.rc_slot = 8u * i + 5u;
         }
     }
 }

@@ -237,7 +237,9 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     // wave issues in order and its own dependent ALU / LDS / scalar chains are the time, not the memory round trips.
     // Semantics per chunk are unchanged: its head lookups see every earlier chunk (those of the same iteration included:
     // lookup and publish alternate chunk by chunk), never its own positions.
+#ifdef ENC_ALIGNED_CANDIDATES
     const bool lowok = b != 0u || D != 0u || ((uint32_t)(uintptr_t)src & 3u) == 0u;  // (3 readable bytes in front of `in`)
+#endif
     uint32_t c0 = D & ~63u;
     v4u v_next[U];  // 16 bytes at every position of the next U chunks
 #pragma unroll
@@ -317,7 +319,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
                 dkA[u][0] = actA[u] ? dA[u] : 0u;
 #pragma unroll
                 for (uint32_t k = 0; k < NC; k++) {
-                    #ifdef ENC_ALIGNED_CANDIDATES  // experiment (profiles/r3q_encal.log: +1 % at level 3, -11 % at levels 5-7)
+#ifdef ENC_ALIGNED_CANDIDATES  // experiment (profiles/r3q_encal.log: +1 % at level 3, -11 % at levels 5-7)
                     c1A[u][k] = e_ld128_al(pme - dkA[u][k], lowok || iA[u] - dkA[u][k] >= 4u);
 #else
                     c1A[u][k] = e_ld128(pme - dkA[u][k]);

@@ -17,14 +17,22 @@ extern "C" __global__ void zxc_decode_blocks_kernel(const uint8_t* comp, const z
 extern "C" __global__ void zxc_decode_blocks_lean_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                          uint8_t* out, int32_t* status, uint32_t block_size,
                                                          const uint32_t* order, uint32_t cap_override, uint32_t trailer_bytes,
-                                                         const zxc_dev_pre_t* pre, const uint8_t* pscratch);
-extern "C" __global__ void zxc_pivco_sections_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, zxc_dev_pre_t* pre, uint32_t* plist,
-                                                     uint8_t* pscratch);
+                                                         const zxc_dev_pre_t* pre);
+extern "C" __global__ void zxc_decode_blocks_lean_pre_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint8_t* out, int32_t* status,
+                                                             uint32_t block_size, uint32_t cap_override, uint32_t trailer_bytes,
+                                                             const zxc_dev_pre_t* pre, const uint8_t* pscratch, const uint32_t* hdr,
+                                                             const uint32_t* entries);
+#define ZXC_SECTIONS_KERNEL(name)                                                                                              \
+    extern "C" __global__ void name(const uint8_t* comp, const zxc_dev_sec_t* secs, uint32_t* hdr, zxc_dev_pre_t* pre, uint8_t* pscratch)
+ZXC_SECTIONS_KERNEL(zxc_pivco_sections_small_kernel);
+ZXC_SECTIONS_KERNEL(zxc_pivco_sections_medium_kernel);
+ZXC_SECTIONS_KERNEL(zxc_pivco_sections_large_kernel);
 extern "C" __global__ void zxc_order_hist_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                  uint32_t block_size, uint32_t* hist);
 extern "C" __global__ void zxc_order_scatter_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                     uint32_t block_size, uint32_t* hist, uint32_t* order, uint32_t* list, uint32_t trailer_bytes,
-                                                    zxc_dev_pre_t* pre, uint32_t* plist, uint32_t pscratch_cap16, uint32_t cap);
+                                                    zxc_dev_pre_t* pre, uint32_t* ctl, uint32_t* pre_entries, zxc_dev_sec_t* secs,
+                                                    uint32_t pscratch_cap16, uint32_t cap);
 extern "C" __global__ void zxc_decode_blocks_dict_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                          uint8_t* out, int32_t* status, uint32_t block_size,
                                                          uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride,
@@ -61,7 +69,7 @@ static struct {
     int wg_per_cu;
     /* launch-order buffers ([128 u32 histogram + cursors | order[n]]), one per stream seen: launches on
      * one stream are ordered, so a stream's buffer is free again when its next launch is enqueued */
-    struct { void* stream; uint32_t* buf; size_t cap; int used; hipStream_t aux; hipEvent_t fork, join; uint8_t* pscratch; size_t pscratch_cap; } ord[ZXC_ORDER_STREAMS];
+    struct { void* stream; uint32_t* buf; size_t cap; int used; hipStream_t aux, aux2; hipEvent_t fork, join, join2, small_done; uint32_t* hint; uint8_t* pscratch; size_t pscratch_cap; } ord[ZXC_ORDER_STREAMS];
 } g_dev[ZXC_MAX_DEVICES];
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 
@@ -236,7 +244,9 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
     const bool want_order = two_pass || (n_jobs > max_slots && !(g_debug_flags & 0x80000000u));
     uint32_t* order = NULL;
     uint32_t* list = NULL;
-    uint32_t* plist = NULL;  // the workgroup section decoder's list, the per-block class records and its scratch
+    uint32_t* ctl = NULL;  // the workgroup section decoders' work lists, the per-block class records and their scratch
+    uint32_t* pre_entries = NULL;
+    zxc_dev_sec_t* secs = NULL;
     zxc_dev_pre_t* pre = NULL;
     uint8_t* pscratch = NULL;
     uint32_t pscratch_cap16 = 0;
@@ -248,7 +258,10 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
             if (!g_dev[dev].ord[i].used) { k = i; g_dev[dev].ord[i].used = 1; g_dev[dev].ord[i].stream = stream; }
         if (k >= 0) {  // (more distinct streams than buffers: one kernel in plain order, still correct)
             auto& o = g_dev[dev].ord[k];
-            const size_t pre_at = (134u + 3u * (size_t)n_jobs + 3u) & ~(size_t)3u;  // (16-byte records)
+            // u32 words: [128 histogram + cursors | list: count, next, n entries | order[n] | ctl (zxc_dev.h) | PRE job indices[n] |
+            // section records, 3 size classes x 2 n x 8 words | pre[n] x 4 words]
+            const size_t ctl_at = 130u + 2u * (size_t)n_jobs, pre_ent_at = ctl_at + ZXC_DEV_CTL_WORDS;
+            const size_t secs_at = (pre_ent_at + (size_t)n_jobs + 7u) & ~(size_t)7u, pre_at = secs_at + 48u * (size_t)n_jobs;
             const size_t want = pre_at + 4u * (size_t)n_jobs;
             if (o.cap < want) {
                 if (o.buf) (void)hipFree(o.buf);
@@ -258,15 +271,32 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
             }
             if (two_pass && !o.aux) {
                 if (hipStreamCreateWithFlags(&o.aux, hipStreamNonBlocking) != hipSuccess) o.aux = NULL;
-                else if (hipEventCreateWithFlags(&o.fork, hipEventDisableTiming) != hipSuccess ||
-                         hipEventCreateWithFlags(&o.join, hipEventDisableTiming) != hipSuccess) {
+                else if (hipStreamCreateWithFlags(&o.aux2, hipStreamNonBlocking) != hipSuccess) {
                     (void)hipStreamDestroy(o.aux);
                     o.aux = NULL;
+                } else if (hipEventCreateWithFlags(&o.fork, hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&o.join, hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&o.join2, hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&o.small_done, hipEventDisableTiming) != hipSuccess) {
+                    (void)hipStreamDestroy(o.aux);
+                    (void)hipStreamDestroy(o.aux2);
+                    o.aux = NULL;
+                }
+                // what the last launch on this stream found (pinned, written by a stream-ordered copy, read without waiting)
+                if (o.aux && !o.hint) {
+                    if (hipHostMalloc((void**)&o.hint, 64, hipHostMallocDefault) == hipSuccess) o.hint[0] = 0xFFFFFFFFu;
+                    else o.hint = NULL;
                 }
             }
+            // The launch plan follows the PREVIOUS launch on this stream: if none of its blocks qualified for the workgroup
+            // section decoders (levels 1-5: the benchmarked case), this one sends every coded block to the full kernel and
+            // launches neither the section kernels nor the lean kernel's second entry — three idle kernels with 14-74 KiB of LDS
+            // per workgroup cost the lean kernel 5-30 % when they ran beside it, 2 % in front of it (profiles/r3z_*). Any plan
+            // decodes any input; the hint only picks the faster one. First launch: the full plan.
+            const bool pre_plan = two_pass && o.aux && (!o.hint || *(volatile uint32_t*)o.hint != 0u);
             // scratch for the sections the workgroup decoder expands ahead of the lean kernel (levels 6-7): what this launch can
             // need at most, capped at 1 GiB (blocks beyond it go to the full kernel and its slot pool); grows, never shrinks
-            if (two_pass && o.aux) {
+            if (pre_plan) {
                 size_t need = (size_t)n_jobs * ((size_t)block_size + block_size / 5u + 256u);
                 if (need > ((size_t)1 << 30)) need = (size_t)1 << 30;
                 if (o.pscratch_cap < need) {
@@ -278,13 +308,17 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
             }
             uint32_t* buf = o.buf;
             if (buf && hipMemsetAsync(buf, 0, 130u * 4u, (hipStream_t)stream) == hipSuccess &&
-                hipMemsetAsync(buf + 130 + 2u * (size_t)n_jobs, 0, 4u * 4u, (hipStream_t)stream) == hipSuccess) {
+                hipMemsetAsync(buf + ctl_at, 0, ZXC_DEV_CTL_WORDS * 4u, (hipStream_t)stream) == hipSuccess) {
                 if (two_pass && o.aux) {
                     list = buf + 128;
-                    plist = buf + 130 + 2u * (size_t)n_jobs;
+                    ctl = buf + ctl_at;
+                    pre_entries = buf + pre_ent_at;
+                    secs = (zxc_dev_sec_t*)(buf + secs_at);
                     pre = (zxc_dev_pre_t*)(buf + pre_at);
-                    pscratch = o.pscratch;
-                    pscratch_cap16 = (uint32_t)(o.pscratch_cap >> 4);
+                    if (pre_plan) {
+                        pscratch = o.pscratch;
+                        pscratch_cap16 = (uint32_t)(o.pscratch_cap >> 4);
+                    }
 #ifdef EXP_NO_PRE  // (experiment: every coded block to the full kernel; the section kernel runs over an empty list)
                     pscratch_cap16 = 0;
 #endif
@@ -294,7 +328,8 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
                                    d_jobs, n_jobs, block_size, buf);
                 hipLaunchKernelGGL(zxc_order_scatter_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream,
                                    (const uint8_t*)d_comp, d_jobs, n_jobs, block_size, buf, buf + 130 + n_jobs, list, verify_trailer ? 4u : 0u,
-                                   pre, plist, pscratch_cap16, cap_override ? cap_override : block_size + 2112u);
+                                   pre, ctl, pre_entries, secs, pscratch_cap16, cap_override ? cap_override : block_size + 2112u);
+                if (ctl && o.hint) (void)hipMemcpyAsync(o.hint, ctl + ZXC_DEV_CTL_WANTED, 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
                 order = buf + 130 + n_jobs;
             }
         }
@@ -305,28 +340,45 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
                            verify_trailer ? 4u : 0u, pool.scratch, stride, g_debug_flags, pool.busy, n_slots,
                            order, cap_override, (const uint8_t*)d_dict, dict_size, (const uint8_t*)d_dict_huf);
     else if (list) {
+        // Streams forked from the caller's by an event and joined back into it (capturable, no host synchronisation).
+        //   no PRE blocks expected:  caller's: lean kernel over every block         | aux: full kernel over its list
+        //   PRE blocks expected:     caller's: section kernels small, medium, large, | aux: lean kernel (LEAN class)
+        //                            then the lean kernel's second entry (PRE blocks) | aux2: full kernel over its list
+        // Fixed grids pull work through counters.
         auto& o = g_dev[dev].ord[k];
+        const uint32_t cus = (uint32_t)g_dev[dev].cus, tb = verify_trailer ? 4u : 0u;
+        hipStream_t s0 = (hipStream_t)stream, s1 = s0, s2 = s0;
         bool forked = false;
-#ifndef EXP_SKIP_FULL  // (experiment: the lean kernel's own time; the blocks on the list stay undecoded)
-        forked = hipEventRecord(o.fork, (hipStream_t)stream) == hipSuccess && hipStreamWaitEvent(o.aux, o.fork, 0) == hipSuccess;
-        // (if the fork fails the full kernel simply runs behind the lean one on the caller's stream)
-        hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(n_jobs < max_slots ? n_jobs : max_slots), dim3(64), 0,
-                           forked ? o.aux : (hipStream_t)stream, (const uint8_t*)d_comp, d_jobs, n_jobs, (uint8_t*)d_out, d_status,
-                           block_size, verify_trailer ? 4u : 0u, pool.scratch, stride, g_debug_flags, pool.busy, n_slots, order,
-                           cap_override, list);
-        if (forked && hipEventRecord(o.join, o.aux) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
+#ifndef EXP_SKIP_FULL  // (experiment: the lean kernel's own time; the other blocks stay undecoded)
+        forked = hipEventRecord(o.fork, s0) == hipSuccess && hipStreamWaitEvent(o.aux, o.fork, 0) == hipSuccess &&
+                 (pscratch_cap16 == 0u || hipStreamWaitEvent(o.aux2, o.fork, 0) == hipSuccess);
+        if (forked) { s1 = o.aux; s2 = pscratch_cap16 ? o.aux2 : o.aux; }  // (if the fork fails everything simply runs on the caller's stream)
+        hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(n_jobs < max_slots ? n_jobs : max_slots), dim3(64), 0, s2, (const uint8_t*)d_comp,
+                           d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, tb, pool.scratch, stride, g_debug_flags, pool.busy, n_slots,
+                           order, cap_override, list);
 #endif
-        // coded sections of the PRE blocks first (a fixed grid pulls them; an empty list costs one idle launch), then every
-        // block that is not on the full kernel's list
-        {
-            const uint32_t wgs = 2u * (uint32_t)g_dev[dev].cus;
-            hipLaunchKernelGGL(zxc_pivco_sections_kernel, dim3(n_jobs < wgs ? n_jobs : wgs), dim3(512), 0, (hipStream_t)stream,
-                               (const uint8_t*)d_comp, d_jobs, pre, plist, pscratch);
+        if (pscratch_cap16) {
+            auto grid = [&](uint32_t per_cu) { const uint32_t g = per_cu * cus; return dim3(2u * n_jobs < g ? 2u * n_jobs : g); };
+            uint32_t* sec_hdr = ctl + ZXC_DEV_CTL_SEC;
+            hipLaunchKernelGGL(zxc_decode_blocks_lean_kernel, dim3(n_jobs), dim3(64), 0, s1, (const uint8_t*)d_comp, d_jobs, n_jobs,
+                               (uint8_t*)d_out, d_status, block_size, order, cap_override, tb, (const zxc_dev_pre_t*)pre);
+            hipLaunchKernelGGL(zxc_pivco_sections_small_kernel, grid(10), dim3(128), 0, s0, (const uint8_t*)d_comp, secs, sec_hdr, pre, pscratch);
+            hipLaunchKernelGGL(zxc_pivco_sections_medium_kernel, grid(3), dim3(256), 0, s0, (const uint8_t*)d_comp, secs + 2u * (size_t)n_jobs,
+                               sec_hdr + 2, pre, pscratch);
+            hipLaunchKernelGGL(zxc_pivco_sections_large_kernel, grid(2), dim3(512), 0, s0, (const uint8_t*)d_comp, secs + 4u * (size_t)n_jobs,
+                               sec_hdr + 4, pre, pscratch);
+            hipLaunchKernelGGL(zxc_decode_blocks_lean_pre_kernel, dim3(n_jobs), dim3(64), 0, s0, (const uint8_t*)d_comp, d_jobs, (uint8_t*)d_out,
+                               d_status, block_size, cap_override, tb, (const zxc_dev_pre_t*)pre, (const uint8_t*)pscratch,
+                               (const uint32_t*)(ctl + ZXC_DEV_CTL_PRE), (const uint32_t*)pre_entries);
+        } else {
+            hipLaunchKernelGGL(zxc_decode_blocks_lean_kernel, dim3(n_jobs), dim3(64), 0, s0, (const uint8_t*)d_comp, d_jobs, n_jobs,
+                               (uint8_t*)d_out, d_status, block_size, order, cap_override, tb, (const zxc_dev_pre_t*)pre);
         }
-        hipLaunchKernelGGL(zxc_decode_blocks_lean_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
-                           d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, order, cap_override, verify_trailer ? 4u : 0u,
-                           (const zxc_dev_pre_t*)pre, (const uint8_t*)pscratch);
-        if (forked && hipStreamWaitEvent((hipStream_t)stream, o.join, 0) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
+        if (forked) {
+            if (hipEventRecord(o.join, s1) != hipSuccess || hipStreamWaitEvent(s0, o.join, 0) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
+            if (s2 != s1 && (hipEventRecord(o.join2, s2) != hipSuccess || hipStreamWaitEvent(s0, o.join2, 0) != hipSuccess))
+                return ZXC_ERROR_GPU_UNAVAILABLE;
+        }
     } else
         hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
                            d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, verify_trailer ? 4u : 0u,
