@@ -227,3 +227,58 @@ def test_overflow_margin_frames_on_emulator(emu, oracle):
         assert st[0] == rc, (name, st[0], rc)
         if rc > 0:
             assert out[:rc] == dec[:rc]
+
+
+def test_section_kernels_every_size_class_and_scratch_overflow_on_emulator(emu, oracle, ref):
+    """Levels 6-7 through the two-pass launch on the emulator: the launch-order pass sorts coded sections into the three size
+    classes of the workgroup section decoder (128 / 256 / 512 threads: wavefronts sharing LDS behind s_barrier) and sends what
+    fits none of them to the one-wave full kernel; every class is exercised. The output is the same when the scratch for
+    decoded sections is missing (every coded block to the full kernel) or runs out half way (both paths in one launch: the
+    launch-order pass hands out scratch per workgroup of 256 blocks)."""
+    import ctypes as C
+    import numpy as np
+    from zxc_amd import corpus
+    L = emu.lib
+    L.emu_last_pre_count.restype = C.c_uint32
+    L.emu_last_deferred_count.restype = C.c_uint32
+    L.emu_last_section_count.restype = C.c_uint32
+    L.emu_last_section_count.argtypes = [C.c_int]
+    L.emu_set_pscratch_bytes.argtypes = [C.c_size_t]
+    rng = np.random.default_rng(7)
+    p = 1.0 / (np.arange(256) + 6.0)
+    oversize = rng.choice(256, size=65536, p=p / p.sum()).astype(np.uint8).tobytes()  # 65536 literals at ~7.2 bits: fits no class
+    large = bytes((rng.choice(48, size=65536) + 32).astype(np.uint8))                  # ~5.6 bits / literal: a 46 KiB body
+    exe = corpus._GEN["exe"](2 * 65536, corpus._rng(3, 1)).tobytes()                   # 32 KiB literal bodies, 3 KiB token bodies
+    data = oversize + large + exe
+    coded = {}
+    try:
+        for level in (6, 7):
+            comp = ref.compress(data, level, 65536, True, False)
+            t = oracle.seek_table(comp)
+            for scratch in (8 << 20, 0):
+                L.emu_set_pscratch_bytes(scratch)
+                jobs, st, out = emu.decode_seekable(comp, t)
+                assert bytes(out) == data and (st == jobs["out_len"]).all(), (level, scratch, st)
+                pre, full = L.emu_last_pre_count(), L.emu_last_deferred_count()
+                if scratch == 0:
+                    assert pre == 0 and full == coded[level], (level, pre, full)
+                else:  # (level 6 codes fewer sections: the exe blocks keep raw literals there)
+                    coded[level] = pre + full
+                    secs = [L.emu_last_section_count(k) for k in range(3)]
+                    assert (pre, full, secs) == ((1, 0, [0, 0, 1]) if level == 6 else (3, 1, [2, 2, 1])), (level, pre, full, secs)
+        # 300 blocks of 4 KiB at level 7: the second workgroup of the launch-order pass finds the scratch used up
+        small = corpus._GEN["exe"](300 * 4096, corpus._rng(4, 1)).tobytes()
+        comp = ref.compress(small, 7, 4096, True, False)
+        t = oracle.seek_table(comp)
+        mixes = 0
+        for scratch in (8 << 20, 850 << 10, 925 << 10, 1000 << 10):
+            L.emu_set_pscratch_bytes(scratch)
+            jobs, st, out = emu.decode_seekable(comp, t)
+            assert bytes(out) == small and (st == jobs["out_len"]).all(), (scratch, st)
+            pre, full = L.emu_last_pre_count(), L.emu_last_deferred_count()
+            assert pre + full == t["n_blocks"], (scratch, pre, full)
+            if scratch == 8 << 20: assert full == 0 and L.emu_last_section_count(0) >= pre, (pre, full)
+            elif pre and full: mixes += 1
+        assert mixes, "no scratch size made the second workgroup overflow"
+    finally:
+        L.emu_set_pscratch_bytes(8 << 20)

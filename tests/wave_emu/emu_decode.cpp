@@ -10,11 +10,12 @@
 namespace emu { void run_wave(const std::function<void()>& body, unsigned block, unsigned grid, int n_lanes); }
 extern char __start_emu_lds[], __stop_emu_lds[];
 
-static uint32_t emu_last_deferred = 0, emu_last_pre = 0;
+static uint32_t emu_last_deferred = 0, emu_last_pre = 0, emu_last_secs[3] = {0, 0, 0};
 static size_t emu_pscratch_bytes = (size_t)8 << 20;  // scratch of the workgroup section decoder (0: every coded block goes to the full kernel)
 extern "C" __attribute__((visibility("default"))) uint32_t emu_last_deferred_count(void) { return emu_last_deferred; }
 extern "C" __attribute__((visibility("default"))) uint32_t emu_last_pre_count(void) { return emu_last_pre; }
 extern "C" __attribute__((visibility("default"))) void emu_set_pscratch_bytes(size_t n) { emu_pscratch_bytes = n; }
+extern "C" __attribute__((visibility("default"))) uint32_t emu_last_section_count(int size_class) { return emu_last_secs[size_class]; }
 
 extern "C" __attribute__((visibility("default")))
 int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_t* jobs, uint32_t n_jobs, uint8_t* out,
@@ -61,6 +62,7 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
         });
         emu_last_pre = ctl[ZXC_DEV_CTL_PRE];
         uint32_t* sec_hdr = ctl.data() + ZXC_DEV_CTL_SEC;
+        for (int k = 0; k < 3; k++) emu_last_secs[k] = sec_hdr[2 * k];
         if (sec_hdr[0]) launch(2, 128, [&] { zxc_pivco_sections_small_kernel(c.data() + 4096, secs.data(), sec_hdr, pre.data(), pscratch.data()); });
         if (sec_hdr[2]) launch(2, 256, [&] { zxc_pivco_sections_medium_kernel(c.data() + 4096, secs.data() + 2u * (size_t)n_jobs, sec_hdr + 2, pre.data(), pscratch.data()); });
         if (sec_hdr[4]) launch(2, 512, [&] { zxc_pivco_sections_large_kernel(c.data() + 4096, secs.data() + 4u * (size_t)n_jobs, sec_hdr + 4, pre.data(), pscratch.data()); });

@@ -342,8 +342,8 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
     else if (list) {
         // Streams forked from the caller's by an event and joined back into it (capturable, no host synchronisation).
         //   no PRE blocks expected:  caller's: lean kernel over every block         | aux: full kernel over its list
-        //   PRE blocks expected:     caller's: section kernels small, medium, large, | aux: lean kernel (LEAN class)
-        //                            then the lean kernel's second entry (PRE blocks) | aux2: full kernel over its list
+        //   PRE blocks expected:     caller's: section kernels medium, large, [small done] | aux: lean kernel (LEAN class)
+        //                            then the lean kernel's second entry (PRE blocks)     | aux2: section kernel small, full kernel
         // Fixed grids pull work through counters.
         auto& o = g_dev[dev].ord[k];
         const uint32_t cus = (uint32_t)g_dev[dev].cus, tb = verify_trailer ? 4u : 0u;
@@ -362,11 +362,14 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
             uint32_t* sec_hdr = ctl + ZXC_DEV_CTL_SEC;
             hipLaunchKernelGGL(zxc_decode_blocks_lean_kernel, dim3(n_jobs), dim3(64), 0, s1, (const uint8_t*)d_comp, d_jobs, n_jobs,
                                (uint8_t*)d_out, d_status, block_size, order, cap_override, tb, (const zxc_dev_pre_t*)pre);
-            hipLaunchKernelGGL(zxc_pivco_sections_small_kernel, grid(10), dim3(128), 0, s0, (const uint8_t*)d_comp, secs, sec_hdr, pre, pscratch);
+            // (the small class runs beside the medium / large ones, on the full kernel's stream: +1 % level 7, +4 % level 6)
+            hipLaunchKernelGGL(zxc_pivco_sections_small_kernel, grid(10), dim3(128), 0, s2, (const uint8_t*)d_comp, secs, sec_hdr, pre, pscratch);
+            if (forked && hipEventRecord(o.small_done, s2) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
             hipLaunchKernelGGL(zxc_pivco_sections_medium_kernel, grid(3), dim3(256), 0, s0, (const uint8_t*)d_comp, secs + 2u * (size_t)n_jobs,
                                sec_hdr + 2, pre, pscratch);
             hipLaunchKernelGGL(zxc_pivco_sections_large_kernel, grid(2), dim3(512), 0, s0, (const uint8_t*)d_comp, secs + 4u * (size_t)n_jobs,
                                sec_hdr + 4, pre, pscratch);
+            if (forked && hipStreamWaitEvent(s0, o.small_done, 0) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
             hipLaunchKernelGGL(zxc_decode_blocks_lean_pre_kernel, dim3(n_jobs), dim3(64), 0, s0, (const uint8_t*)d_comp, d_jobs, (uint8_t*)d_out,
                                d_status, block_size, cap_override, tb, (const zxc_dev_pre_t*)pre, (const uint8_t*)pscratch,
                                (const uint32_t*)(ctl + ZXC_DEV_CTL_PRE), (const uint32_t*)pre_entries);
