@@ -443,8 +443,9 @@ def decode_run(args, level, tiles, steps, warmup, comm, checksum=False, calib_la
                    "parallelism": f"seek-table block range x{world}, no collectives on the data path", "prep": prep},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "zxc_decode_blocks_lean_kernel + zxc_decode_blocks_kernel (coded sections), side by side"
-                               if level <= 5 and not checksum else "zxc_decode_blocks_kernel",
+                     "kernel": "zxc_decode_blocks_lean_kernel + zxc_decode_blocks_kernel (blocks with coded sections), side by side"
+                               if level <= 5 else "zxc_pivco_sections_{small,medium,large}_kernel (coded sections -> scratch), then "
+                                                  "zxc_decode_blocks_lean_pre_kernel; zxc_decode_blocks_kernel beside them for the rest",
                      "avg_launch_ms": round(avg_kernel_s * 1e3, 4), "algorithmic_bytes_per_launch": algo_bytes},
         "bit_exact": "every byte and block status checked before and after the timed loop",
     }

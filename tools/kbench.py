@@ -31,7 +31,7 @@ def run(name, data, level, dbgs, R, bs=65536):
     L = zxc_amd.lib()
     res = []
     for dbg in dbgs:
-        L.zxc_mi355x__set_debug(dbg)
+        zxc_amd.api.set_debug(L, dbg)
         def step(): zxc_amd.decode_blocks_device(d_comp.data_ptr(), d_jobs.data_ptr(), jobs.size, d_out.data_ptr(), d_st.data_ptr(), bs, False, stream)
         step(); torch.cuda.synchronize()
         if dbg == 0:
@@ -43,7 +43,7 @@ def run(name, data, level, dbgs, R, bs=65536):
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 3
         res.append((dbg, ms, R * total / ms / 1e6))
-    L.zxc_mi355x__set_debug(0)
+    zxc_amd.api.set_debug(L, 0)
     print(f"{name:8s} L{level} ratio {total/len(comp):5.2f} blocks {jobs.size:6d} ok={ok} | " +
           " | ".join(f"dbg{d}: {ms:7.2f} ms {g:7.1f} GB/s" for d, ms, g in res), flush=True)
 

@@ -5,9 +5,10 @@ profiles/<tag>_summary.json + <tag>_kernel_stats.csv, and enter the launch's HBM
 
 usage: profile_summary.py <tag> [decode|encode]
 
-Round 3: a decode launch is TWO kernels side by side (zxc_decode_blocks_lean_kernel over every block, zxc_decode_blocks_kernel
-over the list of blocks with coded sections, zxc_hip_shim.hip): counters are summed over both per launch, the launch time is
-the pair's span in the kernel trace. FETCH_SIZE is corrected per access pattern (profiles/r3_gather_calibration.log): the
+Round 3: a decode launch is several kernels (zxc_hip_shim.hip): zxc_decode_blocks_lean_kernel over every block beside
+zxc_decode_blocks_kernel over the list of blocks only it can decode; at levels 6-7 also the three workgroup section kernels
+(zxc_pivco_sections_*) and the lean kernel's second entry over the blocks they prepared. Counters are summed over all of
+them per launch, the launch time is their span in the kernel trace. FETCH_SIZE is corrected per access pattern (profiles/r3_gather_calibration.log): the
 calibration launch of the run (RAW blocks = a 16 B/lane stream of known size) gives the STREAM factor (x1.98: 128-byte
 requests tallied at 64 B); the decode kernels' own reads are single-sector gathers and short runs, for which the counter
 reads x1.0 .. x1.2 of the truth: the raw counter x1.107 (the 16-byte gather figure) is reported, with the bracket."""
@@ -16,7 +17,8 @@ tag = sys.argv[1]
 what = sys.argv[2] if len(sys.argv) > 2 else "decode"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out"); P = os.path.join(ROOT, "profiles"); os.makedirs(P, exist_ok=True)
-DEC = ("zxc_decode_blocks_lean_kernel", "zxc_decode_blocks_kernel")
+DEC = ("zxc_decode_blocks_lean_kernel", "zxc_decode_blocks_kernel", "zxc_decode_blocks_lean_pre_kernel",
+       "zxc_pivco_sections_small_kernel", "zxc_pivco_sections_medium_kernel", "zxc_pivco_sections_large_kernel")
 GATHER_FACTOR, GATHER_BRACKET = 1.107, (1.0, 1.2)
 
 

@@ -303,3 +303,13 @@ def stream_get_decompressed_size(path, library=None):
     L = _bind_stream(library or lib())
     with _File(path, "rb") as fi:
         return int(L.zxc_stream_get_decompressed_size(fi))
+
+
+def set_debug(lib_handle, flags: int) -> None:
+    """tools/ only: the kernel debug switches exist in libraries built with -DZXC_EXPERIMENT (tools/build_variant.sh <name>
+    -DZXC_EXPERIMENT, selected with ZXC_LIB_VARIANT); the release library does not export the setter."""
+    if not hasattr(lib_handle, "zxc_mi355x__set_debug"):
+        if flags:
+            raise RuntimeError("this library was built without -DZXC_EXPERIMENT: set ZXC_LIB_VARIANT to an experiment build")
+        return
+    lib_handle.zxc_mi355x__set_debug(flags)

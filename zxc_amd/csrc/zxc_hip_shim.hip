@@ -431,6 +431,7 @@ static int encode_launch(const void* d_src, uint64_t src_size, uint32_t block_si
     if (dict_size) {  // [dict | block] image per block: the dictionary seeds every block's tables
         hipLaunchKernelGGL(zxc_prepend_dict_kernel, dim3(nb), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_src, src_size,
                            block_size, (const uint8_t*)d_dict, dict_size, (uint8_t*)d_work, nb);
+        if (hipGetLastError() != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;  // (noticed here, not behind the encode launch)
         in = (const uint8_t*)d_work;
     }
     const zxc_enc_level_t lp = zxc_enc_level(level);
