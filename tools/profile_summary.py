@@ -42,8 +42,11 @@ def counters(path, skip_first):
         for k, d in bykern.items():
             ids = sorted(d)
             if skip_first and ids:
+                # bench.py --calib --warmup 2 --steps 5 launches [calibration, 2 warm-up, 5 timed, 1 re-check]; a kernel that is
+                # not part of every launch (the section kernels: the launch plan follows the previous launch) is still in the
+                # five timed ones if in any: the five dispatches in front of its last
                 calib[c] = calib.get(c, 0.0) + d[ids[0]]
-                ids = ids[1:]
+                ids = ids[-6:-1] if len(ids) >= 6 else []
             if ids:
                 tot += sum(d[i] for i in ids) / len(ids)
                 n = max(n, len(ids))
@@ -62,13 +65,22 @@ calib_launch = what == "decode"
 if os.path.exists(kt):
     rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].strip())
                   for r in csv.DictReader(open(kt)) if is_ours(r["Kernel_Name"].split("(")[0].strip()))
-    # group the two decode kernels of one launch: they overlap in time (or touch); the encode kernel is one per launch
+    # group the kernels of one launch. Decode: every launch has exactly one zxc_decode_blocks_lean_kernel dispatch, started right
+    # behind the launch-order pass; a dispatch belongs to the last launch whose lean kernel started no later than 100 us after it.
+    # Encode: one kernel per launch.
     launches = []
-    for s, e, k in rows:
-        if launches and s < launches[-1][1] + 20000 and k not in launches[-1][2]:
-            launches[-1] = (launches[-1][0], max(e, launches[-1][1]), launches[-1][2] + [k])
-        else:
-            launches.append((s, e, [k]))
+    if what == "decode":
+        starts = sorted(s for s, e, k in rows if k == "zxc_decode_blocks_lean_kernel")
+        spans = [[None, None, []] for _ in starts]
+        for s, e, k in rows:
+            j = max((i for i, t in enumerate(starts) if t <= s + 100000), default=0)
+            sp = spans[j]
+            sp[0] = s if sp[0] is None else min(sp[0], s)
+            sp[1] = e if sp[1] is None else max(sp[1], e)
+            sp[2].append(k)
+        launches = [tuple(sp) for sp in spans if sp[0] is not None]
+    else:
+        launches = [(s, e, [k]) for s, e, k in rows]
     durs = [e - s for s, e, _ in launches]
     # bench.py --calib --warmup 2 --steps 5: [calibration, 2 warm-up, 5 timed, 1 re-check]; encode: 1 warm-up, 5 timed, verification decode
     timed = durs[3:8] if calib_launch else durs[1:6]
