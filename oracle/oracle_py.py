@@ -38,7 +38,7 @@ class BlockStats(C.Structure):
 
 class OracleCtx(C.Structure):
     _fields_ = [("block_size", C.c_uint32), ("checksum_enabled", C.c_int), ("dict", C.c_void_p),
-                ("dict_size", C.c_size_t), ("dict_huf", C.c_void_p)]
+                ("dict_size", C.c_size_t), ("dict_huf", C.c_void_p), ("strict_tail", C.c_int)]
 
 
 class Oracle:
@@ -73,9 +73,10 @@ class Oracle:
                                      dict_, len(dict_) if dict_ else 0, dict_huf)
         return rc, out.raw[:max(rc, 0)]
 
-    def decode_block(self, blk: bytes, block_size: int, cap=None, checksum=False):
+    def decode_block(self, blk: bytes, block_size: int, cap=None, checksum=False, strict_tail=False):
+        """strict_tail: the reference's zxc_decompress_block_safe decoders (exact checks only)."""
         cap = block_size + 2112 if cap is None else cap
-        ctx = OracleCtx(block_size, int(checksum), None, 0, None)
+        ctx = OracleCtx(block_size, int(checksum), None, 0, None, int(strict_tail))
         out = C.create_string_buffer(cap + 1)
         rc = self.lib.zxo_decode_block(C.byref(ctx), blk, len(blk), out, cap)
         return rc, out.raw[:max(rc, 0)]

@@ -449,7 +449,32 @@ typedef struct {
     size_t cap;
     size_t dict_size;
     size_t p, lp;
+    int fourx; /* the reference is still in its 4x-unrolled loops (see reserve_4x) */
 } seq_state_t;
+
+/* The reference's accept / reject decisions are those of an exact decoder EXCEPT inside its 4x-unrolled loops
+ * (GLO src/lib/zxc_decompress.c:1050-1103, GHI :1296-1384; non-"safe" variants only): there a sequence with a
+ * varint-extended length is refused with OVERFLOW unless the worst-case inline output of the batch's remaining
+ * sequences + ZXC_PAD_SIZE still fits behind it, and its literals + the remaining sequences' raw literal fields fit
+ * the literal stream (DECODE_GLO_SEQ :626-656, DECODE_GHI_SEQ :701-727). Which sequences run in 4x batches: a batch of
+ * four starts at every multiple of 4 while n_seq >= 4 remain, d_ptr < d_end - D and l_ptr < l_end - Lm (Lm < sz_lit);
+ * all three are monotone in the cursors, so the 4x batches are a PREFIX of the sequence list (the SAFE -> FAST switch
+ * at d_bounds keeps the grouping; GHI's 1x offset-validating loop :1322-1357 only runs once the 4x condition has failed
+ * for good). `W` = worst inline output per sequence (33 GLO / 513 GHI), D = 168 / 2112, Lm = 56 / 1016.
+ * Called in front of every sequence i with its final ll / ml (ml includes the minimum match length);
+ * `raw_ll_rest` = sum of the RAW literal-length fields of the sequences behind i in its batch. */
+static int reserve_4x(seq_state_t* s, uint32_t i, uint32_t n_seq, int esc_l, int esc_m, uint64_t ll, uint64_t ml,
+                      uint64_t raw_ll_rest, uint32_t W, uint32_t D, uint32_t Lm) {
+    if (!s->fourx) return ZXO_OK;
+    if ((i & 3u) == 0u)
+        s->fourx = (n_seq - i >= 4u) && ((uint64_t)s->p + D < s->cap) && (s->n_lit > Lm) && (s->lp < s->n_lit - Lm);
+    if (!s->fourx || !(esc_l || esc_m)) return ZXO_OK;
+    const uint32_t n_rem = 3u - (i & 3u);
+    if (esc_l && ll + raw_ll_rest > s->n_lit - s->lp) return ZXO_E_OVERFLOW;
+    /* (:645-648 with the raw ml, :657-660 with the extended one: the union is the test on the final lengths) */
+    if (ll + ml + (uint64_t)n_rem * W + 32u > s->cap - s->p) return ZXO_E_OVERFLOW;
+    return ZXO_OK;
+}
 
 static int emit_sequence(seq_state_t* s, uint64_t ll, uint64_t ml, uint32_t off) {
     if (ll + ml > s->cap - s->p || ll > s->n_lit - s->lp) return ZXO_E_OVERFLOW;
@@ -545,13 +570,20 @@ static int decode_glo(const zxo_ctx_t* ctx, const uint8_t* src, size_t n, uint8_
             st->lit_bytes = lit_comp; st->tok_bytes = tok_comp; st->off_bytes = (uint32_t)sz_off;
             st->extra_bytes = (uint32_t)(ext_end - ext);
         }
-        seq_state_t s = {lit, lit_n, ext, ext_end, win, cap, ctx->dict_size, 0, 0};
+        seq_state_t s = {lit, lit_n, ext, ext_end, win, cap, ctx->dict_size, 0, 0, !ctx->strict_tail};
         for (uint32_t i = 0; i < n_seq; i++) {
             uint64_t ll = tok[i] >> 4, ml = tok[i] & 15;
+            const int esc_l = ll == 15, esc_m = ml == 15;
             const uint32_t off = 1u + (enc_off ? offs[i] : le16(offs + 2 * (size_t)i));
             if (ll == 15) { ll += read_varint(&s.extras, s.extras_end); if (st) st->n_varints++; }
             if (ml == 15) { ml += read_varint(&s.extras, s.extras_end); if (st) st->n_varints++; }
             ml += ZXO_MIN_MATCH;
+            {
+                uint64_t rest = 0;
+                for (uint32_t j = i + 1; j <= (i | 3u) && j < n_seq; j++) rest += tok[j] >> 4;
+                rc = reserve_4x(&s, i, n_seq, esc_l, esc_m, ll, ml, rest, 33u, 168u, 56u);
+                if (rc != ZXO_OK) goto out;
+            }
             if (st) {
                 int lg = 0;
                 while ((1u << lg) < off) lg++;
@@ -582,15 +614,22 @@ static int decode_ghi(const zxo_ctx_t* ctx, const uint8_t* src, size_t n, uint8_
     const uint8_t* seqs = lit + n_lit;
     const uint8_t* ext = seqs + (size_t)n_seq * 4;
     if (st) { st->lit_bytes = n_lit; st->tok_bytes = n_seq * 4; st->extra_bytes = (uint32_t)(src + n - ext); }
-    seq_state_t s = {lit, n_lit, ext, src + n, win, cap, ctx->dict_size, 0, 0};
+    seq_state_t s = {lit, n_lit, ext, src + n, win, cap, ctx->dict_size, 0, 0, !ctx->strict_tail};
     for (uint32_t i = 0; i < n_seq; i++) {
         const uint32_t w = le32(seqs + 4 * (size_t)i);
         uint64_t ll = w >> 24;
         const uint32_t mb = (w >> 16) & 0xFF;
         uint64_t ml = mb + ZXO_MIN_MATCH;
+        const int esc_l = ll == 255, esc_m = mb == 255;
         if (ll == 255) { ll += read_varint(&s.extras, s.extras_end); if (st) st->n_varints++; }
         if (mb == 255) { ml += read_varint(&s.extras, s.extras_end); if (st) st->n_varints++; }
         const uint32_t off = (w & 0xFFFF) + 1;
+        {
+            uint64_t rest = 0;
+            for (uint32_t j = i + 1; j <= (i | 3u) && j < n_seq; j++) rest += seqs[4 * (size_t)j + 3];
+            const int r4 = reserve_4x(&s, i, n_seq, esc_l, esc_m, ll, ml, rest, 513u, 2112u, 1016u);
+            if (r4 != ZXO_OK) return r4;
+        }
         if (st) {
             int lg = 0;
             while ((1u << lg) < off) lg++;

@@ -52,6 +52,9 @@ typedef struct {
     const uint8_t* dict;       /* dictionary content or NULL */
     size_t dict_size;
     const uint8_t* dict_huf;   /* 128-byte shared literal code lengths or NULL */
+    int strict_tail;           /* 1: the reference's "safe" decoders (zxc_decompress_block_safe: exact capacity, a 4x batch
+                                * that would overflow rolls back to the exact loops); 0: every other entry point, whose 4x
+                                * batches answer OVERFLOW from their output reserve (zxc_decompress.c:626-656) */
 } zxo_ctx_t;
 
 typedef struct {

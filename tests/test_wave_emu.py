@@ -215,18 +215,44 @@ def test_encoder_pivco_sections_on_emulator(emu, ref, oracle):
 
 
 def test_overflow_margin_frames_on_emulator(emu, oracle):
-    """The constructed frames of tests/golden/craft.py (the reference's OVERFLOW-by-batch-reserve cases): the kernels give the
-    block the oracle's verdict — decoded to 6140 bytes, or BAD_OFFSET."""
+    """The constructed frames of tests/golden/craft.py around the reference's 4x-batch output reserve (both sides of it, GLO and
+    GHI): the kernels give every block the oracle's verdict, which test_oracle_golden.py pins to the reference's."""
     import craft
     import emu_py
+    codes = set()
     for name, (f, want) in craft.overflow_margin_frames(oracle).items():
         jobs, bs, ck, total = emu_py.frame_jobs(f)
         jobs["out_len"] = 6208  # (the host API decodes an irregular frame with one capacity-sized slot per block)
         st, out = emu.decode_jobs(f, jobs, 6208, bs)
         rc, dec = oracle.decode_block(f[16:16 + int(jobs["comp_size"][0])], bs, cap=6208)
         assert st[0] == rc, (name, st[0], rc)
+        assert rc == want or name == "size_mismatch" or want == -8
+        codes.add(rc if rc < 0 else "ok")
         if rc > 0:
             assert out[:rc] == dec[:rc]
+    assert codes == {"ok", -10}
+
+
+def test_random_blocks_around_the_reserve_on_emulator(emu, oracle):
+    """craft.random_reserve_blocks (blocks that end around the capacity / the end of their literal stream, cut batches included;
+    tests/test_oracle_golden.py pins the oracle to the reference on 1 500 of them): kernels == oracle, code and bytes, with
+    the frame decoders' capacity and with the strict capacity of zxc_decompress_block_safe."""
+    import craft
+    import emu_py
+    codes = {}
+    frames = craft.random_reserve_blocks(oracle, 23, 260)
+    for strict in (False, True):
+        for f, blk in frames[:260 if not strict else 90]:
+            jobs, bs, ck, total = emu_py.frame_jobs(f)
+            cap = 4096 if strict else 6208
+            jobs["out_len"] = cap
+            st, out = emu.decode_jobs(f, jobs, 6208, bs, cap_override=cap if strict else 0)
+            rc, dec = oracle.decode_block(blk, bs, cap=cap, strict_tail=strict)
+            assert st[0] == rc, (strict, st[0], rc)
+            if rc > 0:
+                assert out[:rc] == dec[:rc]
+            codes[(strict, rc if rc < 0 else "ok")] = codes.get((strict, rc if rc < 0 else "ok"), 0) + 1
+    assert codes.get((False, "ok"), 0) > 20 and codes.get((False, -10), 0) > 20 and codes.get((True, -10), 0) > 5, codes
 
 
 def test_section_kernels_every_size_class_and_scratch_overflow_on_emulator(emu, oracle, ref):

@@ -17,6 +17,10 @@ extern "C" __attribute__((visibility("default"))) uint32_t emu_last_pre_count(vo
 extern "C" __attribute__((visibility("default"))) void emu_set_pscratch_bytes(size_t n) { emu_pscratch_bytes = n; }
 extern "C" __attribute__((visibility("default"))) uint32_t emu_last_section_count(int size_class) { return emu_last_secs[size_class]; }
 
+// the strict per-block capacity of zxc_decompress_block_safe (the kernels' cap_override argument; 0 = block_size + 2112)
+static uint32_t emu_cap_override = 0;
+extern "C" __attribute__((visibility("default"))) void emu_set_cap_override(uint32_t cap) { emu_cap_override = cap; }
+
 extern "C" __attribute__((visibility("default")))
 int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_t* jobs, uint32_t n_jobs, uint8_t* out,
                       size_t out_bytes, int32_t* status, uint32_t block_size, int verify_trailer, const uint8_t* dict,
@@ -37,7 +41,7 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
             emu::run_wave([&] {
                 zxc_decode_blocks_dict_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size,
                                               verify_trailer ? 4u : 0u, scratch.data(), stride, 0u, busy.data(), n_slots,
-                                              nullptr, 0u, dptr, dict_size, dict_huf);
+                                              nullptr, emu_cap_override, dptr, dict_size, dict_huf);
             }, b, n_jobs, 64);
         }
     } else {
@@ -58,7 +62,7 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
         launch(g256, 256, [&] { zxc_order_hist_kernel(c.data() + 4096, jobs, n_jobs, block_size, hist.data()); });
         launch(g256, 256, [&] {
             zxc_order_scatter_kernel(c.data() + 4096, jobs, n_jobs, block_size, hist.data(), order.data(), list.data(), tb, pre.data(), ctl.data(),
-                                     pre_entries.data(), secs.data(), (uint32_t)(emu_pscratch_bytes >> 4), block_size + 2112u);
+                                     pre_entries.data(), secs.data(), (uint32_t)(emu_pscratch_bytes >> 4), emu_cap_override ? emu_cap_override : block_size + 2112u);
         });
         emu_last_pre = ctl[ZXC_DEV_CTL_PRE];
         uint32_t* sec_hdr = ctl.data() + ZXC_DEV_CTL_SEC;
@@ -67,10 +71,10 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
         if (sec_hdr[2]) launch(2, 256, [&] { zxc_pivco_sections_medium_kernel(c.data() + 4096, secs.data() + 2u * (size_t)n_jobs, sec_hdr + 2, pre.data(), pscratch.data()); });
         if (sec_hdr[4]) launch(2, 512, [&] { zxc_pivco_sections_large_kernel(c.data() + 4096, secs.data() + 4u * (size_t)n_jobs, sec_hdr + 4, pre.data(), pscratch.data()); });
         launch(n_jobs, 64, [&] {
-            zxc_decode_blocks_lean_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, order.data(), 0u, tb, pre.data());
+            zxc_decode_blocks_lean_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, order.data(), emu_cap_override, tb, pre.data());
         });
         if (ctl[ZXC_DEV_CTL_PRE]) launch(n_jobs, 64, [&] {
-            zxc_decode_blocks_lean_pre_kernel(c.data() + 4096, jobs, o.data() + 4096, status, block_size, 0u, tb, pre.data(), pscratch.data(),
+            zxc_decode_blocks_lean_pre_kernel(c.data() + 4096, jobs, o.data() + 4096, status, block_size, emu_cap_override, tb, pre.data(), pscratch.data(),
                                               ctl.data() + ZXC_DEV_CTL_PRE, pre_entries.data());
         });
         emu_last_deferred = list[0];
@@ -79,7 +83,7 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
             memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));
             emu::run_wave([&] {
                 zxc_decode_blocks_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, verify_trailer ? 4u : 0u, scratch.data(),
-                                         stride, 0u, busy.data(), n_slots, order.data(), 0u, list.data());
+                                         stride, 0u, busy.data(), n_slots, order.data(), emu_cap_override, list.data());
             }, b, grid, 64);
         }
     }

@@ -24,13 +24,16 @@ class Emu:
                                         C.c_void_p, C.c_uint32, C.c_int, C.c_char_p, C.c_uint32, C.c_char_p]
 
     def decode_jobs(self, comp: bytes, jobs: np.ndarray, out_bytes: int, block_size: int, verify_trailer=False,
-                    dict_=None, dict_huf=None):
-        """Runs every job through one emulated wavefront. -> (status int32[n], output bytes)."""
+                    dict_=None, dict_huf=None, cap_override=0):
+        """Runs every job through one emulated wavefront. -> (status int32[n], output bytes).
+        cap_override: the strict per-block capacity of zxc_decompress_block_safe (0: block_size + 2112)."""
         jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
+        self.lib.emu_set_cap_override(int(cap_override))
         out = C.create_string_buffer(max(out_bytes, 1))
         status = np.full(jobs.size, -999, dtype=np.int32)
         self.lib.emu_decode_blocks(comp, len(comp), jobs.ctypes.data, jobs.size, out, out_bytes, status.ctypes.data,
                                    block_size, int(verify_trailer), dict_, len(dict_) if dict_ else 0, dict_huf)
+        self.lib.emu_set_cap_override(0)
         return status, out.raw[:out_bytes]
 
     def decode_seekable(self, comp: bytes, table: dict, **kw):

@@ -471,8 +471,11 @@ __device__ __forceinline__ void load_seq_raw(const LzStreams& S, uint32_t s, uin
 // stale window data one lap old that nothing can reference any more: ring_lo = z_new - RING_BYTES).
 template <bool DICT, bool GHI>
 __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __restrict__ dst, uint32_t out_len, uint32_t cap,
-                             WaveLds& L, int lane) {
+                             WaveLds& L, int lane, const bool strict) {
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    // the reference's 4x-batch reserve: see run_sequences_lean (zxc_seq_lean.inc)
+    const uint32_t RW = GHI ? 513u : 33u, RD = GHI ? 2112u : 168u, RLM = GHI ? 1016u : 56u;
+    bool carry4x = true;
     const uint32_t n_total = S.n_seq + 1u;  // + pseudo sequence carrying the trailing literals
     const uint32_t n_lit = S.n_lit;
     Out O;
@@ -573,7 +576,22 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
         const bool pseudo = valid & !real;  // whatever literals are left
         const bool lit_over = lst > n_lit;
         const uint32_t lit_left = n_lit - lst;
-        const bool ovf_real = (est > cap) | (len > cap - est) | lit_over | (ll > lit_left);
+        bool ovf_real = (est > cap) | (len > cap - est) | lit_over | (ll > lit_left);
+        bool cut4 = false;
+        if (!strict) {
+            const uint32_t gi = s & 3u;
+            const int gl = lane - (int)gi;  // my group's first sequence (< 0: in an earlier batch)
+            const uint32_t g_est = __shfl(est, gl < 0 ? 0 : gl), g_lst = __shfl(lst, gl < 0 ? 0 : gl);
+            bool g4 = gl >= 0 ? (g_est + RD < cap && n_lit > RLM && g_lst < n_lit - RLM) : carry4x;
+            g4 = g4 && real && S.n_seq - (s - gi) >= 4u;
+            const uint32_t rawl = GHI ? raw_t >> 24 : raw_t >> 4;
+            const uint32_t r1 = __shfl(rawl, (lane + 1) & 63), r2 = __shfl(rawl, (lane + 2) & 63), r3 = __shfl(rawl, (lane + 3) & 63);
+            const uint32_t rest = (gi < 3u ? r1 : 0u) + (gi < 2u ? r2 : 0u) + (gi < 1u ? r3 : 0u);
+            const bool r_lit = escL && !lit_over && ll + rest > lit_left;
+            const bool r_dst = (escL | escM) && est <= cap && len + (3u - gi) * RW + 32u > cap - est;
+            ovf_real |= g4 & (r_lit | r_dst);
+            cut4 = seq_base + 64u < S.n_seq && lane + (int)(3u - gi) > 63;  // judged by the batch that holds the whole group
+        }
         const bool ovf_pseudo = (est > cap) | lit_over | (lit_left > cap - est);
         const bool bad_off = off > est + ll + (DICT ? S.dict_size : 0u);
         int err = 0;
@@ -584,7 +602,8 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
         const uint32_t E = est + len;
 
         // how many leading sequences fit a tile of TILE_MAX bytes (errors first, in order)
-        const uint64_t fits = __ballot(valid && err == 0 && (E - p) <= TILE_MAX);
+        if (cut4) err = 0;
+        const uint64_t fits = __ballot(valid && !cut4 && err == 0 && (E - p) <= TILE_MAX);
         const uint64_t em = __ballot(err != 0);
         uint32_t k = (uint32_t)__ffsll((unsigned long long)~fits);  // 1-based index of first non-fitting lane
         k = k ? k - 1u : 64u;
@@ -941,6 +960,14 @@ __device__ __forceinline__ int run_sequences(const LzStreams& S, uint8_t* __rest
 #ifdef EXP_EXTRA_SLEEP  // experiment only: the wave sleeps 64 x EXP_EXTRA_SLEEP clocks per batch (is it latency-bound?)
         __builtin_amdgcn_s_sleep(EXP_EXTRA_SLEEP);
 #endif
+        if (!strict && ((seq_base + k) & 3u) != 0u) {
+            const uint32_t g = (seq_base + k) & ~3u;  // the group the next batch starts inside
+            if (g >= seq_base) {
+                const uint32_t ge = (uint32_t)__builtin_amdgcn_readlane((int)est, (int)(g - seq_base)),
+                               gl = (uint32_t)__builtin_amdgcn_readlane((int)lst, (int)(g - seq_base));
+                carry4x = ge + RD < cap && n_lit > RLM && gl < n_lit - RLM;
+            }
+        }
         seq_base += k;
         raw_t = nraw_t;
         raw_o = nraw_o;
@@ -1098,7 +1125,7 @@ __device__ int rle_expand(const uint8_t* __restrict__ r_, uint32_t rsize, uint8_
 template <bool DICT>
 __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t comp_sz, bool ghi, uint8_t* dst, uint32_t out_len,
                                uint32_t cap, uint32_t block_size, ScratchPool& pool, WaveLds& L, int lane,
-                               uint32_t dbg, const uint8_t* dict, uint32_t dict_size, const uint8_t* dict_huf) {
+                               uint32_t dbg, const uint8_t* dict, uint32_t dict_size, const uint8_t* dict_huf, const bool strict) {
     if (comp_sz < 12u) return E_BAD_HEADER;
     LzStreams S;
     S.dict = dict;
@@ -1117,8 +1144,8 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
         S.off8 = 0;
         S.ext = S.tok + 4ull * S.n_seq;
         S.ext_size = avail - (uint32_t)consumed;
-        if (!DICT) return run_sequences_lean<true>(S, dst, out_len, cap, reinterpret_cast<LeanLds&>(L), lane);
-        return run_sequences<DICT, true>(S, dst, out_len, cap, L, lane);
+        if (!DICT) return run_sequences_lean<true>(S, dst, out_len, cap, reinterpret_cast<LeanLds&>(L), lane, strict);
+        return run_sequences<DICT, true>(S, dst, out_len, cap, L, lane, strict);
     }
     const uint32_t desc = (enc_lit != 0u ? 4u : 0u) + (enc_tok == 2u ? 4u : 0u);
     if (comp_sz < 12u + desc) return E_BAD_HEADER;
@@ -1186,8 +1213,8 @@ __device__ __forceinline__ int decode_lz_block(const uint8_t* data, uint32_t com
 #ifdef ZXC_EXPERIMENT
     if (dbg & DBG_NO_SEQ) return (int)out_len;
 #endif
-    if (!DICT) return run_sequences_lean<false>(S, dst, out_len, cap, reinterpret_cast<LeanLds&>(L), lane);
-    return run_sequences<DICT, false>(S, dst, out_len, cap, L, lane);
+    if (!DICT) return run_sequences_lean<false>(S, dst, out_len, cap, reinterpret_cast<LeanLds&>(L), lane, strict);
+    return run_sequences<DICT, false>(S, dst, out_len, cap, L, lane, strict);
 }
 
 #ifndef WAVES_PER_SIMD
@@ -1240,7 +1267,7 @@ __device__ __forceinline__ void decode_one_block(const uint8_t* __restrict__ com
             rc = E_BAD_CHECKSUM;  // per-block checksum of the compressed payload (zxc_decompress.c:1662-1666)
         } else if (type == 1u || type == 2u) {
             rc = decode_lz_block<DICT>(src + 8, comp_sz, type == 2u, dst, out_len, cap, block_size, pool, L, lane, dbg, dict,
-                                 dict_size, dict_huf);
+                                 dict_size, dict_huf, cap_override != 0u);
             scratch_release(pool, lane);
         } else if (type == 0u) {  // RAW: stored bytes
             if (comp_sz > cap) rc = E_DST_TOO_SMALL;
@@ -1408,9 +1435,9 @@ __device__ __forceinline__ void lean_one_block(const uint8_t* __restrict__ comp,
         } else if (trailer_bytes && wave_checksum32(src + 8, comp_sz, lane) != uni(ld32(src + 8 + comp_sz))) {
             rc = E_BAD_CHECKSUM;  // per-block checksum of the compressed payload (zxc_decompress.c:1662-1666)
         } else if (PRE) {  // (a GLO block, by classify_block: nothing else is compiled into the second entry)
-            rc = type == 1u ? decode_lz_block_lean(src + 8, comp_sz, false, dst, out_len, cap, L, lane, pre + b, pscratch) : ZXC_DEV_E_INTERNAL;
+            rc = type == 1u ? decode_lz_block_lean(src + 8, comp_sz, false, dst, out_len, cap, L, lane, pre + b, pscratch, cap_override != 0u) : ZXC_DEV_E_INTERNAL;
         } else if (type == 1u || type == 2u) {
-            rc = decode_lz_block_lean(src + 8, comp_sz, type == 2u, dst, out_len, cap, L, lane, nullptr, pscratch);
+            rc = decode_lz_block_lean(src + 8, comp_sz, type == 2u, dst, out_len, cap, L, lane, nullptr, pscratch, cap_override != 0u);
         } else if (type == 0u) {  // RAW: stored bytes
             if (comp_sz > cap) rc = E_DST_TOO_SMALL;
             else {
@@ -1542,8 +1569,17 @@ zxc_order_scatter_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* 
         bool fit = true;
         wg_base[0] = 0;
         if (wg_cnt[0]) {
-            wg_base[0] = atomicAdd(ctl + ZXC_DEV_CTL_CURSOR, wg_cnt[0]);
-            fit = (uint64_t)wg_base[0] + wg_cnt[0] <= pscratch_cap16;  // (scratch exhausted: this workgroup's PRE blocks go to the full kernel and its slot pool)
+            // The cursor only moves while it is inside the scratch, so it can never wrap (a launch of ~870 K level-7 blocks would
+            // add up to more than 2^32 units otherwise): the first request that does not fit leaves it beyond the capacity, and
+            // exhaustion is sticky from then on. (scratch exhausted: this workgroup's PRE blocks go to the full kernel and its slot pool)
+            uint32_t old = __hip_atomic_load(ctl + ZXC_DEV_CTL_CURSOR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {
+                if (old > pscratch_cap16) { fit = false; break; }
+                const uint32_t seen = atomicCAS(ctl + ZXC_DEV_CTL_CURSOR, old, old + wg_cnt[0]);  // (old <= 2^26, a workgroup asks for < 2^27)
+                if (seen == old) { fit = (uint64_t)old + wg_cnt[0] <= pscratch_cap16; break; }
+                old = seen;
+            }
+            wg_base[0] = old;
         }
         wg_fit = fit ? 1u : 0u;
         if (wg_cnt[1]) atomicAdd(ctl + ZXC_DEV_CTL_WANTED, wg_cnt[1]);

@@ -969,10 +969,11 @@ int64_t zxc_seekable_decompress_range(zxc_seekable* s, void* dst, const size_t d
 
 /* The multi-threaded range decode (reference: zxc_seekable.c:1033-1108 plans one job per block and lets n_threads workers
  * pull them). Here a block is a workgroup's work, so host threads add nothing on ONE device; what they are for is
- * SEVERAL devices: the covered blocks are cut into min(n_threads, devices) contiguous parts, one host thread + stream +
- * staging arena per part, each on its own device; n_threads == 0 takes every device. The devices are those of
- * ZXC_MI355X_DEVICES (a comma-separated list of ordinals; an ordinal may repeat: two workers, two streams on that
- * device) or, without it, all of them. First failing part in block order wins, like the reference's job scan. */
+ * SEVERAL devices, and only on request: with ZXC_MI355X_DEVICES set (a comma-separated list of ordinals; an ordinal may
+ * repeat: two workers, two streams on that device) the covered blocks are cut into min(n_threads, listed devices)
+ * contiguous parts (n_threads == 0: all listed), one host thread + stream + staging arena per part. Without the variable
+ * the call stays on the calling thread's current device (zxc_mi355x_set_device): in a one-rank-per-GPU job a rank must
+ * never touch the other ranks' GPUs. First failing part in block order wins, like the reference's job scan. */
 typedef struct {
     zxc_seekable* s;
     uint8_t* dst;
@@ -993,20 +994,18 @@ static void* seek_part_main(void* p) {
     return NULL;
 }
 static int device_list(int* devs, int cap) {
-    const int count = zxc_mi355x_device_count();
+    int count = zxc_mi355x_device_count();
+    if (count > HOST_MAX_DEVICES) count = HOST_MAX_DEVICES; /* (ordinals index per-device tables of that size) */
     int n = 0;
     const char* e = getenv("ZXC_MI355X_DEVICES");
-    if (e && *e) {
-        while (*e && n < cap) {
-            char* end = NULL;
-            const long v = strtol(e, &end, 10);
-            if (end == e) break;
-            if (v >= 0 && v < count) devs[n++] = (int)v;
-            e = (*end == ',') ? end + 1 : end;
-            if (*end != ',' && *end != 0) break;
-        }
-    } else {
-        for (int i = 0; i < count && n < cap; i++) devs[n++] = i;
+    if (!e || !*e) return 0; /* no explicit opt-in: no fan-out (the caller's current device) */
+    while (*e && n < cap) {
+        char* end = NULL;
+        const long v = strtol(e, &end, 10);
+        if (end == e) break;
+        if (v >= 0 && v < count) devs[n++] = (int)v;
+        e = (*end == ',') ? end + 1 : end;
+        if (*end != ',' && *end != 0) break;
     }
     return n;
 }
