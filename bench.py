@@ -50,7 +50,10 @@ def tile_bytes(tile, block_size, pool):
     return corpus.synth_silesia_tile(tile, pool=pool)[:n], "synth_silesia tiles (per-tile xor-rotated seed)"
 
 
-def build_rank_corpus(first, last, level, block_size, pool, dev, checksum=False):
+CPU_BASELINE_TILES = 4  # the cpu_baseline sample: ONE reference-written archive of this many corpus tiles
+
+
+def build_rank_corpus(first, last, level, block_size, pool, dev, checksum=False, baseline_tiles=0):
     """Blocks [first, last) of the global corpus, encoded by the unmodified reference (the metric is defined on
     archives written by the reference encoder: "silesia.tar at -3"; untimed input preparation). Only the tiles
     this range touches are generated; compressed blocks and plaintext go straight to HBM, tile by tile, so the
@@ -71,10 +74,15 @@ def build_rank_corpus(first, last, level, block_size, pool, dev, checksum=False)
     first_tile_comp = None
     src = ""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    with ThreadPoolExecutor(max_workers=max(1, min(16, len(tiles), (os.cpu_count() or 1) // world // 2))) as tp:
+    base_fut, base_data = None, []
+    with ThreadPoolExecutor(max_workers=max(1, min(16, len(tiles) + 1, (os.cpu_count() or 1) // world // 2))) as tp:
         futs = []
         for t in tiles:
             data, src = tile_bytes(t, block_size, pool)
+            if len(base_data) < baseline_tiles:  # the CPU baseline's archive: the first tiles as ONE seekable archive
+                base_data.append(data)
+                if len(base_data) == min(baseline_tiles, len(tiles)):
+                    base_fut = tp.submit(ref.compress, b"".join(base_data), level, block_size, True, False)
             lo, hi = max(first, t * tb) - t * tb, min(last, (t + 1) * tb) - t * tb
             wants.append(torch.frombuffer(bytearray(data[lo * block_size: hi * block_size]), dtype=torch.uint8).to(dev))
             futs.append((lo, hi, tp.submit(ref.compress, data, level, block_size, True, checksum)))
@@ -90,6 +98,9 @@ def build_rank_corpus(first, last, level, block_size, pool, dev, checksum=False)
     d_comp = torch.cat(regions + [torch.zeros(256, dtype=torch.uint8, device=dev)])  # (+ slack for 16-byte reads)
     d_want = torch.cat(wants)
     info = dict(prep_s=round(time.time() - t0, 1), tiles=len(tiles), encoder="reference _ref", source=src)
+    if base_fut is not None:
+        first_tile_comp = base_fut.result()
+        info["prep_s"] = round(time.time() - t0, 1)
     return d_comp, np.concatenate(sizes_all), d_want, hdr, eof, info, first_tile_comp
 
 
@@ -120,7 +131,7 @@ def open_global_table(all_sizes, block_size, hdr, eof, total_decoded):
     return zxc_amd.Seekable(reader=reader, size=size)
 
 
-def cpu_baseline(comp, total, budget_s=12.0):
+def cpu_baseline(comp, total, budget_s=12.0, what="corpus tile 0"):
     """The reference's own parallel seekable decode on this box's host cores (bounded sample)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
@@ -142,8 +153,8 @@ def cpu_baseline(comp, total, budget_s=12.0):
         rc, _ = ref.seekable_range_mt(comp, 0, total, 1, dst=dst)
         dt1 = time.perf_counter() - t0
         return {"value": round(total / best / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "reference",
-                "sample": f"zxc_seekable_decompress_range_mt over corpus tile 0 ({total >> 20} MiB decoded), "
-                          f"T={cores} threads, best of {iters}",
+                "sample": f"zxc_seekable_decompress_range_mt over {what} ({total >> 20} MiB decoded, "
+                          f"{(total + 65535) >> 16} blocks of 64 KiB), T={cores} threads, best of {iters}",
                 "single_thread_GBs": round(total / dt1 / 1e9, 3)}
     o = oracle_py.Oracle()
     n = min(total, 8 << 20)
@@ -353,7 +364,8 @@ def decode_run(args, level, tiles, steps, warmup, comm, checksum=False, calib_la
 
     # ---- workload: this rank's block range of the one corpus
     n_total, first, last = rank_partition(rank, world, tiles, bs)
-    d_comp, my_sizes, d_want, hdr, eof, prep, tile0_comp = build_rank_corpus(first, last, level, bs, pool, dev, checksum)
+    base_tiles = min(CPU_BASELINE_TILES, tiles) if (with_cpu_baseline and world == 1) else 0
+    d_comp, my_sizes, d_want, hdr, eof, prep, tile0_comp = build_rank_corpus(first, last, level, bs, pool, dev, checksum, base_tiles)
     pool.close()
     if world > 1:  # control plane only: every rank learns the whole seek table (4 B per block)
         gathered = [None] * world
@@ -452,25 +464,110 @@ def decode_run(args, level, tiles, steps, warmup, comm, checksum=False, calib_la
     if calib:
         line["calibration"] = calib
     if with_cpu_baseline and world == 1:
-        line["cpu_baseline"] = cpu_baseline(tile0_comp, int.from_bytes(tile0_comp[-12:-4], "little"), cpu_budget_s)
+        line["cpu_baseline"] = cpu_baseline(tile0_comp, int.from_bytes(tile0_comp[-12:-4], "little"), cpu_budget_s,
+                                            f"corpus tiles 0-{base_tiles - 1} as one archive" if base_tiles > 1 else "corpus tile 0")
     del d_comp, d_want, d_out
     torch.cuda.empty_cache()
     return line
 
 
+def kernel_sources_hash():
+    """sha256 over the device sources (zxc_amd/csrc/*.hip, *.inc, *.h, sorted by name): what a traffic profile belongs to.
+    (Content hash, not a git object id: .git does not travel to the GPU box.)"""
+    import hashlib
+    d = os.path.join(ROOT, "zxc_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".inc", ".h")):
+            h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read() + b"\0")
+    return h.hexdigest()[:16]
+
+
 def profiled_traffic(what, **workload):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (FETCH_SIZE / WRITE_SIZE in
-    separate --pmc runs, counters corrected as profiles/r3_gather_calibration.log prescribes). NOT measured in this run: a
-    constant reported only when the run's workload equals the profiled one (the object says which file), else null."""
+    separate --pmc runs, counters corrected as profiles/r3_gather_calibration.log prescribes; tools/profile.sh +
+    tools/profile_summary.py write profiles/r4_traffic.json). NOT measured in this run: a constant, reported only when the
+    run's workload equals the profiled one AND the device sources are byte for byte the ones that were profiled
+    (`kernels` = kernel_sources_hash() at profiling time) — else null, never a stale number (VERDICT r3 weak #5)."""
     try:
-        tab = json.load(open(os.path.join(ROOT, "profiles", "r3_traffic.json")))
+        tab = json.load(open(os.path.join(ROOT, "profiles", "r4_traffic.json")))
         e = tab.get(what)
-        if e and all(e["workload"].get(k) == v for k, v in workload.items()):
+        if e and e.get("kernels") == kernel_sources_hash() and all(e["workload"].get(k) == v for k, v in workload.items()):
             return {"bytes_per_launch": e["bytes_per_launch"], "read": e["read"], "write": e["write"], "source": e["source"],
-                    "measured_in_this_run": False}
+                    "kernels": e["kernels"], "measured_in_this_run": False}
     except Exception:
         pass
     return None
+
+
+def host_api_run(args, dev):
+    """SURVEY.md §8(d) "also report end-to-end through the C API (incl. H2D / D2H) separately": the drop-in entry points on
+    PAGEABLE host buffers, PCIe both ways inside the timed region — zxc_compress + zxc_decompress of a 1 GiB frame (five corpus
+    tiles; reference entry points src/lib/zxc_dispatch.c:658-840, :842-1005) and zxc_seekable_decompress_range[_mt] over a
+    reference-written archive of one tile (src/lib/zxc_seekable.c:695-785, :999-1108). Every output byte compared. Never `value`."""
+    import multiprocessing as mp
+    import zxc_amd
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    bs = args.block_size
+    pool = mp.get_context("spawn").Pool(max(1, min(48, os.cpu_count() or 1)))
+    tiles = [tile_bytes(t, bs, pool)[0] for t in range(5)]
+    pool.close()
+    data = b"".join(tiles)[:1 << 30]
+    L = zxc_amd.lib()
+    L.zxc_compress_bound.restype = C.c_uint64
+    L.zxc_compress_bound.argtypes = [C.c_size_t]
+    L.zxc_compress.restype = C.c_int64
+    L.zxc_decompress.restype = C.c_int64
+
+    class COpts(C.Structure):  # include/zxc_opts.h (reference include/zxc_opts.h:58-78)
+        _fields_ = [("n_threads", C.c_int), ("level", C.c_int), ("block_size", C.c_size_t), ("checksum_enabled", C.c_int),
+                    ("seekable", C.c_int), ("dict", C.c_void_p), ("dict_size", C.c_size_t), ("dict_huf", C.c_void_p),
+                    ("progress_cb", C.c_void_p), ("user_data", C.c_void_p)]
+    L.zxc_compress.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(COpts)]
+    L.zxc_decompress.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    o = COpts(level=3, block_size=bs, seekable=1)
+    cap = int(L.zxc_compress_bound(len(data)))
+    cbuf = C.create_string_buffer(cap)
+    dbuf = C.create_string_buffer(len(data))
+    res = {"note": "pageable host buffers in and out, H2D + D2H inside the timed region; best of 3 after one warm-up call",
+           "frame_bytes": len(data), "block_size": bs}
+
+    def best_of(fn, n=3):
+        fn()
+        b = None
+        for _ in range(n):
+            t0 = time.perf_counter()
+            r = fn()
+            dt = time.perf_counter() - t0
+            b = dt if b is None or dt < b else b
+        return r, b
+    csize, dt = best_of(lambda: L.zxc_compress(data, len(data), cbuf, cap, C.byref(o)))
+    assert csize > 0, csize
+    res["zxc_compress"] = {"value": round(len(data) / dt / 1e9, 2), "unit": "GB/s of source", "level": 3, "ms": round(dt * 1e3, 1),
+                           "ratio": round(len(data) / csize, 3)}
+    comp = cbuf.raw[:csize]
+    rc, dt = best_of(lambda: L.zxc_decompress(comp, csize, dbuf, len(data), None))
+    assert rc == len(data) and dbuf.raw == data, "zxc_decompress: bytes differ"
+    res["zxc_decompress"] = {"value": round(len(data) / dt / 1e9, 2), "unit": "GB/s decoded", "ms": round(dt * 1e3, 1),
+                             "checked": "every byte == source"}
+    del cbuf, comp
+    if oracle_py.Ref.available():
+        t0d = tiles[0]
+        arc = oracle_py.Ref().compress(t0d, 3, bs, True, False)
+        sk = zxc_amd.Seekable(arc)
+        out = C.create_string_buffer(len(t0d))
+        for name, nt in (("zxc_seekable_decompress_range", None), ("zxc_seekable_decompress_range_mt", 0)):
+            def call():
+                if nt is None:
+                    return L.zxc_seekable_decompress_range(sk._h, out, len(t0d), 0, len(t0d))
+                return L.zxc_seekable_decompress_range_mt(sk._h, out, len(t0d), 0, len(t0d), nt)
+            rc, dt = best_of(call)
+            assert rc == len(t0d) and out.raw == t0d, name
+            res[name] = {"value": round(len(t0d) / dt / 1e9, 2), "unit": "GB/s decoded", "ms": round(dt * 1e3, 1),
+                         "archive": f"corpus tile 0 written by the reference ({len(t0d) >> 20} MiB decoded)", "checked": "every byte"}
+        sk.close()
+    return res
 
 
 def launch_ranks(args):
@@ -583,6 +680,7 @@ def main():
                 sec["level7"] = decode_run(args, 7, args.l7_tiles, max(5, args.steps // 2), 2, comm,
                                            with_cpu_baseline=not args.no_cpu_baseline, cpu_budget_s=6.0)
                 sec["encode_l3"] = encode_run(args, 3, args.enc_mib, max(3, args.steps // 4), 1, comm, not args.no_cpu_baseline)
+                sec["host_api"] = host_api_run(args, torch.device("cuda", local))
                 line["secondary"] = sec
         if rank == 0:
             print(json.dumps(line))

@@ -233,6 +233,39 @@ def test_overflow_margin_frames_on_emulator(emu, oracle):
     assert codes == {"ok", -10}
 
 
+def test_rle_blocks_run_in_the_lean_kernel_and_fail_like_the_oracle(emu, oracle):
+    """Round 4: blocks with RLE-coded literals and raw tokens are expanded and decoded by the lean kernel (slot of the scratch pool)
+    instead of the one-wave full kernel. The golden RLE archive leaves the full kernel's list empty; 400 mutations of it (header
+    fields, RLE tokens, sequences) get the oracle's status and bytes whichever kernel ends up with the block."""
+    import ctypes as C
+    import emu_py
+    comp = read("format/11_glo_rle.zxc")
+    jobs, bs, ck, total = emu_py.frame_jobs(comp)
+    rc, want = oracle.decompress(comp, total)
+    st, out = emu.decode_jobs(comp, jobs, total, bs)
+    emu.lib.emu_last_deferred_count.restype = C.c_uint32
+    assert rc == total and out == want and emu.lib.emu_last_deferred_count() == 0
+    assert comp[int(jobs["comp_off"][0]) + 16] == 1  # enc_lit = RLE
+    rng = random.Random(9)
+    codes = set()
+    j = jobs[0]
+    for it in range(400):
+        m = bytearray(comp)
+        lo = int(j["comp_off"]) + (8 if it % 3 else 8 + 28)  # (every third: behind the headers only — RLE tokens and sequences)
+        for _ in range(rng.choice((1, 1, 2, 3))):
+            m[lo + rng.randrange(int(j["comp_size"]) - (lo - int(j["comp_off"])))] ^= 1 << rng.randrange(8)
+        m = bytes(m)
+        st, out = emu.decode_jobs(m, jobs, total, bs)
+        blk = m[int(j["comp_off"]):int(j["comp_off"]) + int(j["comp_size"])]
+        rc, dec = oracle.decode_block(blk, bs)
+        assert st[0] == rc, (it, st[0], rc)
+        codes.add(rc if rc < 0 else "ok")
+        if rc >= 0:
+            n = min(rc, int(j["out_len"]))
+            assert out[:n] == dec[:n], it
+    assert {"ok", -8}.issubset(codes), codes
+
+
 def test_random_blocks_around_the_reserve_on_emulator(emu, oracle):
     """craft.random_reserve_blocks (blocks that end around the capacity / the end of their literal stream, cut batches included;
     tests/test_oracle_golden.py pins the oracle to the reference on 1 500 of them): kernels == oracle, code and bytes, with

@@ -15,6 +15,8 @@ static size_t emu_pscratch_bytes = (size_t)8 << 20;  // scratch of the workgroup
 extern "C" __attribute__((visibility("default"))) uint32_t emu_last_deferred_count(void) { return emu_last_deferred; }
 extern "C" __attribute__((visibility("default"))) uint32_t emu_last_pre_count(void) { return emu_last_pre; }
 extern "C" __attribute__((visibility("default"))) void emu_set_pscratch_bytes(size_t n) { emu_pscratch_bytes = n; }
+static size_t emu_rscratch_bytes = (size_t)4 << 20;  // scratch for the expanded literals of LEAN_RLE blocks (0: they go to the full kernel)
+extern "C" __attribute__((visibility("default"))) void emu_set_rscratch_bytes(size_t n) { emu_rscratch_bytes = n; }
 extern "C" __attribute__((visibility("default"))) uint32_t emu_last_section_count(int size_class) { return emu_last_secs[size_class]; }
 
 // the strict per-block capacity of zxc_decompress_block_safe (the kernels' cap_override argument; 0 = block_size + 2112)
@@ -35,7 +37,15 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
     std::vector<uint8_t> dct;
     const uint8_t* dptr = nullptr;
     if (dict && dict_size) { dct.assign(dict_size + 8192, 0xBB); memcpy(dct.data() + 4096, dict, dict_size); dptr = dct.data() + 4096; }
-    if (dptr || dict_huf) {
+    if (emu_cap_override && !(dptr || dict_huf)) {  // strict capacity: the full kernel alone, one block per workgroup (zxc_hip_shim.hip)
+        for (uint32_t b = 0; b < n_jobs; b++) {
+            memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));
+            emu::run_wave([&] {
+                zxc_decode_blocks_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, verify_trailer ? 4u : 0u, scratch.data(),
+                                         stride, 0u, busy.data(), n_slots, nullptr, emu_cap_override, nullptr);
+            }, b, n_jobs, 64);
+        }
+    } else if (dptr || dict_huf) {
         for (uint32_t b = 0; b < n_jobs; b++) {
             memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));  // LDS is not zero at launch
             emu::run_wave([&] {
@@ -53,6 +63,7 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
         std::vector<zxc_dev_pre_t> pre(n_jobs);
         std::vector<zxc_dev_sec_t> secs(6u * (size_t)n_jobs);
         std::vector<uint8_t> pscratch(emu_pscratch_bytes + 4096, 0xC3);
+        std::vector<uint8_t> rscratch(emu_rscratch_bytes + 4096, 0xC7);  // expanded literals of the LEAN_RLE blocks
         auto launch = [&](unsigned grid, int threads, const std::function<void()>& k) {
             for (unsigned g = 0; g < grid; g++) {
                 memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));  // LDS is not zero at launch
@@ -62,7 +73,8 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
         launch(g256, 256, [&] { zxc_order_hist_kernel(c.data() + 4096, jobs, n_jobs, block_size, hist.data()); });
         launch(g256, 256, [&] {
             zxc_order_scatter_kernel(c.data() + 4096, jobs, n_jobs, block_size, hist.data(), order.data(), list.data(), tb, pre.data(), ctl.data(),
-                                     pre_entries.data(), secs.data(), (uint32_t)(emu_pscratch_bytes >> 4), emu_cap_override ? emu_cap_override : block_size + 2112u);
+                                     pre_entries.data(), secs.data(), (uint32_t)(emu_pscratch_bytes >> 4), emu_cap_override ? emu_cap_override : block_size + 2112u,
+                                     (uint32_t)(emu_rscratch_bytes >> 4));
         });
         emu_last_pre = ctl[ZXC_DEV_CTL_PRE];
         uint32_t* sec_hdr = ctl.data() + ZXC_DEV_CTL_SEC;
@@ -70,8 +82,11 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
         if (sec_hdr[0]) launch(2, 128, [&] { zxc_pivco_sections_small_kernel(c.data() + 4096, secs.data(), sec_hdr, pre.data(), pscratch.data()); });
         if (sec_hdr[2]) launch(2, 256, [&] { zxc_pivco_sections_medium_kernel(c.data() + 4096, secs.data() + 2u * (size_t)n_jobs, sec_hdr + 2, pre.data(), pscratch.data()); });
         if (sec_hdr[4]) launch(2, 512, [&] { zxc_pivco_sections_large_kernel(c.data() + 4096, secs.data() + 4u * (size_t)n_jobs, sec_hdr + 4, pre.data(), pscratch.data()); });
+        if (ctl[ZXC_DEV_CTL_RLE_LIST]) launch(2, 64, [&] {
+            zxc_rle_expand_kernel(c.data() + 4096, jobs, pre.data(), rscratch.data(), ctl.data() + ZXC_DEV_CTL_RLE_LIST, pre_entries.data() + n_jobs - 1u);
+        });
         launch(n_jobs, 64, [&] {
-            zxc_decode_blocks_lean_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, order.data(), emu_cap_override, tb, pre.data());
+            zxc_decode_blocks_lean_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, order.data(), emu_cap_override, tb, pre.data(), rscratch.data());
         });
         if (ctl[ZXC_DEV_CTL_PRE]) launch(n_jobs, 64, [&] {
             zxc_decode_blocks_lean_pre_kernel(c.data() + 4096, jobs, o.data() + 4096, status, block_size, emu_cap_override, tb, pre.data(), pscratch.data(),

@@ -7,7 +7,7 @@ import re, sys, collections
 path, kern = sys.argv[1], sys.argv[2]
 lines = open(path).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith(kern + ":"))
-end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))  # (a kernel has several s_endpgm: early returns)
 CHEAP = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32",
          "v_mov_b32", "v_min_u32", "v_max_u32", "v_min_i32", "v_max_i32", "v_not_b32", "v_add_co_u32", "v_addc_co_u32", "v_sub_co_u32",
          "v_subb_co_u32", "v_cndmask_b32", "v_bfrev_b32", "v_ffbh_u32", "v_ffbl_b32", "v_xnor_b32", "v_mul_u32_u24", "v_mul_i32_i24"}

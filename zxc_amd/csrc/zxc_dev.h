@@ -17,6 +17,9 @@
 #define ZXC_DEV_CLS_LEAN 0u /* raw sections (and every block the lean kernel can name an error for) */
 #define ZXC_DEV_CLS_FULL 1u /* RLE literals, oversized or malformed coded sections: the one-wave full kernel */
 #define ZXC_DEV_CLS_PRE 2u
+#define ZXC_DEV_CLS_LEAN_RLE 3u /* RLE-coded literals, raw tokens, header valid: zxc_rle_expand_kernel expands the literals into the
+                                 * block's share of the launch's RLE scratch (lit_off, 16-byte units; verdict in rc_lit), the lean
+                                 * kernel then runs the block like one with raw sections */
 typedef struct {
     uint32_t lit_off; /* decoded literals at scratch + 16 * lit_off + 16 */
     uint32_t tok_off; /* decoded tokens at scratch + 16 * tok_off */
@@ -36,6 +39,9 @@ typedef struct {          /* one coded section on a size class's work list */
 #define ZXC_DEV_CTL_CURSOR 2u  /* scratch handed out so far, 16-byte units */
 #define ZXC_DEV_CTL_WANTED 3u  /* blocks that qualify for PRE, scratch or no scratch (the next launch's plan: zxc_hip_shim.hip) */
 #define ZXC_DEV_CTL_SEC 4u     /* [4 + 2 c] sections listed in size class c, [5 + 2 c] next to hand out */
+#define ZXC_DEV_CTL_RLE_CURSOR 10u /* RLE scratch handed out so far, 16-byte units (saturating like CURSOR) */
+#define ZXC_DEV_CTL_RLE_WANTED 11u /* RLE scratch all LEAN_RLE candidates of the launch would take (sizes the next launch's buffer) */
+#define ZXC_DEV_CTL_RLE_LIST 12u   /* [12] LEAN_RLE blocks listed (job indices from the END of the PRE entries array, backwards), [13] next to hand out */
 
 /* Scratch slot of a block with a coded (RLE / PivCo) section, shared by the kernels, the shim's pool and the CPU emulator:
  * [0, R) expanded literals (from +16) | [R, 2R) the section decoder's odd-depth level buffer | [2R, stride) decoded tokens

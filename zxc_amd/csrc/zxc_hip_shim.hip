@@ -17,11 +17,13 @@ extern "C" __global__ void zxc_decode_blocks_kernel(const uint8_t* comp, const z
 extern "C" __global__ void zxc_decode_blocks_lean_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                          uint8_t* out, int32_t* status, uint32_t block_size,
                                                          const uint32_t* order, uint32_t cap_override, uint32_t trailer_bytes,
-                                                         const zxc_dev_pre_t* pre);
+                                                         const zxc_dev_pre_t* pre, uint8_t* rscratch);
 extern "C" __global__ void zxc_decode_blocks_lean_pre_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint8_t* out, int32_t* status,
                                                              uint32_t block_size, uint32_t cap_override, uint32_t trailer_bytes,
                                                              const zxc_dev_pre_t* pre, const uint8_t* pscratch, const uint32_t* hdr,
                                                              const uint32_t* entries);
+extern "C" __global__ void zxc_rle_expand_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, zxc_dev_pre_t* pre, uint8_t* rscratch,
+                                                 uint32_t* hdr, const uint32_t* entries_last);
 #define ZXC_SECTIONS_KERNEL(name)                                                                                              \
     extern "C" __global__ void name(const uint8_t* comp, const zxc_dev_sec_t* secs, uint32_t* hdr, zxc_dev_pre_t* pre, uint8_t* pscratch)
 ZXC_SECTIONS_KERNEL(zxc_pivco_sections_small_kernel);
@@ -32,7 +34,7 @@ extern "C" __global__ void zxc_order_hist_kernel(const uint8_t* comp, const zxc_
 extern "C" __global__ void zxc_order_scatter_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                     uint32_t block_size, uint32_t* hist, uint32_t* order, uint32_t* list, uint32_t trailer_bytes,
                                                     zxc_dev_pre_t* pre, uint32_t* ctl, uint32_t* pre_entries, zxc_dev_sec_t* secs,
-                                                    uint32_t pscratch_cap16, uint32_t cap);
+                                                    uint32_t pscratch_cap16, uint32_t cap, uint32_t rscratch_cap16);
 extern "C" __global__ void zxc_decode_blocks_dict_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs,
                                                          uint8_t* out, int32_t* status, uint32_t block_size,
                                                          uint32_t trailer_bytes, uint8_t* scratch, uint32_t scratch_stride,
@@ -69,7 +71,7 @@ static struct {
     int wg_per_cu;
     /* launch-order buffers ([128 u32 histogram + cursors | order[n]]), one per stream seen: launches on
      * one stream are ordered, so a stream's buffer is free again when its next launch is enqueued */
-    struct { void* stream; uint32_t* buf; size_t cap; int used; hipStream_t aux, aux2; hipEvent_t fork, join, join2, small_done; uint32_t* hint; uint8_t* pscratch; size_t pscratch_cap; } ord[ZXC_ORDER_STREAMS];
+    struct { void* stream; uint32_t* buf; size_t cap; int used; hipStream_t aux, aux2; hipEvent_t fork, join, join2, small_done; uint32_t* hint; uint8_t* pscratch; size_t pscratch_cap; uint8_t* rscratch; size_t rscratch_cap; } ord[ZXC_ORDER_STREAMS];
 } g_dev[ZXC_MAX_DEVICES];
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 
@@ -174,8 +176,10 @@ void zxc_mi355x_release_cached(void) {
         auto& o = g_dev[dev].ord[i];
         if (o.buf) (void)hipFree(o.buf);
         if (o.pscratch) (void)hipFree(o.pscratch);
+        if (o.rscratch) (void)hipFree(o.rscratch);
         o.buf = NULL; o.cap = 0;
         o.pscratch = NULL; o.pscratch_cap = 0;
+        o.rscratch = NULL; o.rscratch_cap = 0;
     }
     pthread_mutex_unlock(&g_lock);
 }
@@ -240,7 +244,9 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
     // back into it (event fork / join: capturable, no host synchronisation). Per-stream buffer:
     // [128 u32 histogram + cursors | list: count, next, n entries | order[n]]; heaviest-first dispatch order (a launch ends when its slowest
     // block ends).
-    const bool two_pass = !d_dict && !d_dict_huf && !(g_debug_flags & 0x40000000u);
+    // (not with the strict capacity of zxc_decompress_block_safe either: the lean kernel is compiled for the frame decoders'
+    // semantics, 4x-batch reserve included; the full kernel takes the flag at run time)
+    const bool two_pass = !d_dict && !d_dict_huf && !cap_override && !(g_debug_flags & 0x40000000u);
     const bool want_order = two_pass || (n_jobs > max_slots && !(g_debug_flags & 0x80000000u));
     uint32_t* order = NULL;
     uint32_t* list = NULL;
@@ -250,6 +256,8 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
     zxc_dev_pre_t* pre = NULL;
     uint8_t* pscratch = NULL;
     uint32_t pscratch_cap16 = 0;
+    uint8_t* rscratch = NULL;  // expanded literals of the blocks with RLE-coded literals that the lean kernel takes (LEAN_RLE)
+    uint32_t rscratch_cap16 = 0;
     int k = -1;
     if (want_order) {
         for (int i = 0; i < ZXC_ORDER_STREAMS; i++)
@@ -284,7 +292,7 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
                 }
                 // what the last launch on this stream found (pinned, written by a stream-ordered copy, read without waiting)
                 if (o.aux && !o.hint) {
-                    if (hipHostMalloc((void**)&o.hint, 64, hipHostMallocDefault) == hipSuccess) o.hint[0] = 0xFFFFFFFFu;
+                    if (hipHostMalloc((void**)&o.hint, 64, hipHostMallocDefault) == hipSuccess) { o.hint[0] = 0xFFFFFFFFu; o.hint[1] = 0u; }
                     else o.hint = NULL;
                 }
             }
@@ -304,6 +312,26 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
                     o.pscratch = NULL;
                     o.pscratch_cap = 0;
                     if (hipMalloc((void**)&o.pscratch, need) == hipSuccess) o.pscratch_cap = need;
+                }
+            }
+            // The same way for the RLE scratch: hint[1] = 16-byte units the previous launch's LEAN_RLE candidates wanted (+ 1 per
+            // workgroup that had any). None / first launch: no buffer, such blocks go to the full kernel as in round 3; else
+            // a quarter more than last time (blocks that do not fit fall back to the full kernel one workgroup of 256 at a time).
+            if (two_pass && o.aux && o.hint) {
+                const uint32_t want16 = *(volatile uint32_t*)(o.hint + 1);
+                if (want16 != 0u) {
+                    size_t need = ((size_t)want16 * 16u * 5u / 4u + 65536u) & ~(size_t)4095u;
+                    const size_t most = (size_t)n_jobs * ((size_t)block_size + 96u);
+                    if (need > most) need = most;
+                    if (need > ((size_t)1 << 30)) need = (size_t)1 << 30;
+                    if (o.rscratch_cap < need) {
+                        if (o.rscratch) (void)hipFree(o.rscratch);
+                        o.rscratch = NULL;
+                        o.rscratch_cap = 0;
+                        if (hipMalloc((void**)&o.rscratch, need) == hipSuccess) o.rscratch_cap = need;
+                    }
+                    rscratch = o.rscratch;
+                    rscratch_cap16 = (uint32_t)(o.rscratch_cap >> 4);
                 }
             }
             uint32_t* buf = o.buf;
@@ -328,8 +356,12 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
                                    d_jobs, n_jobs, block_size, buf);
                 hipLaunchKernelGGL(zxc_order_scatter_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream,
                                    (const uint8_t*)d_comp, d_jobs, n_jobs, block_size, buf, buf + 130 + n_jobs, list, verify_trailer ? 4u : 0u,
-                                   pre, ctl, pre_entries, secs, pscratch_cap16, cap_override ? cap_override : block_size + 2112u);
-                if (ctl && o.hint) (void)hipMemcpyAsync(o.hint, ctl + ZXC_DEV_CTL_WANTED, 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+                                   pre, ctl, pre_entries, secs, pscratch_cap16, cap_override ? cap_override : block_size + 2112u,
+                                   list ? rscratch_cap16 : 0u);
+                if (ctl && o.hint) {
+                    (void)hipMemcpyAsync(o.hint, ctl + ZXC_DEV_CTL_WANTED, 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+                    (void)hipMemcpyAsync(o.hint + 1, ctl + ZXC_DEV_CTL_RLE_WANTED, 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+                }
                 order = buf + 130 + n_jobs;
             }
         }
@@ -357,6 +389,11 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
             if (forked) { (void)hipStreamSynchronize(o.aux); (void)hipStreamSynchronize(o.aux2); }
             return ZXC_ERROR_GPU_UNAVAILABLE;
         };
+        auto launch_rle = [&](hipStream_t st) {  // the LEAN_RLE blocks' literals, in front of the lean kernel on its stream
+            if (rscratch_cap16)
+                hipLaunchKernelGGL(zxc_rle_expand_kernel, dim3(n_jobs < 8u * cus ? n_jobs : 8u * cus), dim3(64), 0, st, (const uint8_t*)d_comp, d_jobs,
+                                   pre, rscratch, ctl + ZXC_DEV_CTL_RLE_LIST, (const uint32_t*)(pre_entries + n_jobs - 1u));
+        };
         auto launch_full = [&]() {
 #ifndef EXP_SKIP_FULL  // (experiment: the lean kernel's own time; the other blocks stay undecoded)
             hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(n_jobs < max_slots ? n_jobs : max_slots), dim3(64), 0, s2, (const uint8_t*)d_comp,
@@ -372,8 +409,9 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
         if (pscratch_cap16) {
             auto grid = [&](uint32_t per_cu) { const uint32_t g = per_cu * cus; return dim3(2u * n_jobs < g ? 2u * n_jobs : g); };
             uint32_t* sec_hdr = ctl + ZXC_DEV_CTL_SEC;
+            launch_rle(s1);
             hipLaunchKernelGGL(zxc_decode_blocks_lean_kernel, dim3(n_jobs), dim3(64), 0, s1, (const uint8_t*)d_comp, d_jobs, n_jobs,
-                               (uint8_t*)d_out, d_status, block_size, order, cap_override, tb, (const zxc_dev_pre_t*)pre);
+                               (uint8_t*)d_out, d_status, block_size, order, cap_override, tb, (const zxc_dev_pre_t*)pre, rscratch);
             // (the small class runs beside the medium / large ones, on its own stream: +1 % level 7, +4 % level 6)
             hipLaunchKernelGGL(zxc_pivco_sections_small_kernel, grid(10), dim3(128), 0, s2, (const uint8_t*)d_comp, secs, sec_hdr, pre, pscratch);
             if (forked && hipEventRecord(o.small_done, s2) != hipSuccess) return fail();
@@ -388,8 +426,9 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
                                (const uint32_t*)(ctl + ZXC_DEV_CTL_PRE), (const uint32_t*)pre_entries);
         } else {
             launch_full();
+            launch_rle(s0);
             hipLaunchKernelGGL(zxc_decode_blocks_lean_kernel, dim3(n_jobs), dim3(64), 0, s0, (const uint8_t*)d_comp, d_jobs, n_jobs,
-                               (uint8_t*)d_out, d_status, block_size, order, cap_override, tb, (const zxc_dev_pre_t*)pre);
+                               (uint8_t*)d_out, d_status, block_size, order, cap_override, tb, (const zxc_dev_pre_t*)pre, rscratch);
         }
         if (forked) {
             if (hipEventRecord(o.join, s1) != hipSuccess || hipStreamWaitEvent(s0, o.join, 0) != hipSuccess) return fail();
