@@ -82,9 +82,11 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
         if (sec_hdr[0]) launch(2, 128, [&] { zxc_pivco_sections_small_kernel(c.data() + 4096, secs.data(), sec_hdr, pre.data(), pscratch.data()); });
         if (sec_hdr[2]) launch(2, 256, [&] { zxc_pivco_sections_medium_kernel(c.data() + 4096, secs.data() + 2u * (size_t)n_jobs, sec_hdr + 2, pre.data(), pscratch.data()); });
         if (sec_hdr[4]) launch(2, 512, [&] { zxc_pivco_sections_large_kernel(c.data() + 4096, secs.data() + 4u * (size_t)n_jobs, sec_hdr + 4, pre.data(), pscratch.data()); });
-        if (ctl[ZXC_DEV_CTL_RLE_LIST]) launch(2, 64, [&] {
-            zxc_rle_expand_kernel(c.data() + 4096, jobs, pre.data(), rscratch.data(), ctl.data() + ZXC_DEV_CTL_RLE_LIST, pre_entries.data() + n_jobs - 1u);
-        });
+        if (ctl[ZXC_DEV_CTL_RLE_LIST]) {
+            launch(3u, 64, [&] {
+                zxc_rle_expand_kernel(c.data() + 4096, jobs, pre.data(), rscratch.data(), ctl.data() + ZXC_DEV_CTL_RLE_LIST, pre_entries.data() + n_jobs - 1u);
+            });
+        }
         launch(n_jobs, 64, [&] {
             zxc_decode_blocks_lean_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, order.data(), emu_cap_override, tb, pre.data(), rscratch.data());
         });

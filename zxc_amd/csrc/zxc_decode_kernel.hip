@@ -1509,20 +1509,19 @@ zxc_decode_blocks_lean_kernel(const uint8_t* __restrict__ comp, const zxc_dev_jo
     lean_one_block<false>(comp, jobs, out, status, block_size, cap_override, trailer_bytes, b, nullptr, nullptr, L, threadIdx.x, rle_slot, rle_rc);
 }
 
-// The literals of the launch's LEAN_RLE blocks, expanded into their shares of rscratch: a fixed grid of wavefronts pulls the
-// blocks from the list zxc_order_scatter_kernel wrote (hdr = {entries, next}; job indices from entries_last backwards). Its own
-// kernel, in front of the lean kernel on the same stream: inlined into the lean kernel the expansion cost every block of the
-// launch 5 % (register pressure: profiles/r4a_rle_in_lean_ab.log), beside it in the one-wave full kernel 4 % (round 3).
+// The literals of the launch's LEAN_RLE blocks, expanded into their shares of rscratch: the blocks are listed by
+// zxc_order_scatter_kernel (hdr[0] = entries; job indices from entries_last backwards). A small fixed grid in front of the lean
+// kernel on its stream, block i to workgroup i mod grid (no atomic hand-out: a wave-uniform pull loop around a one-lane atomic
+// hung on the device here, profiles/r4b_rle_variants.log). What round 4 measured on the way (same log): the expansion inlined
+// into the lean kernel costs every block of a launch 5 % (a third inlined copy of the executor); the blocks on a helper stream
+// beside the lean kernel (own entry behind the expansion) start late and end the launch, like the one-wave full kernel did in
+// round 3 (these blocks are the corpus' heaviest: ~5 500 sequences, ~400 literal bytes in ~40 RLE tokens).
 extern "C" __global__ void __launch_bounds__(64)
 zxc_rle_expand_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, zxc_dev_pre_t* __restrict__ pre,
-                      uint8_t* __restrict__ rscratch, uint32_t* __restrict__ hdr, const uint32_t* __restrict__ entries_last) {
+                      uint8_t* __restrict__ rscratch, const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ entries_last) {
     const int lane = threadIdx.x;
-    const uint32_t n = uni(__hip_atomic_load(hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    for (;;) {
-        uint32_t i = 0;
-        if (lane == 0) i = atomicAdd(hdr + 1, 1u);
-        i = uni(i);
-        if (i >= n) break;
+    const uint32_t n = uni(hdr[0]);
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {  // (a small fixed grid; block i to workgroup i mod grid)
         const uint32_t b = uni(*(entries_last - i));
         const uint8_t* src = comp + jobs[b].comp_off;
         const uint32_t n_lit = uni(ld32(src + 12));

@@ -23,7 +23,7 @@ extern "C" __global__ void zxc_decode_blocks_lean_pre_kernel(const uint8_t* comp
                                                              const zxc_dev_pre_t* pre, const uint8_t* pscratch, const uint32_t* hdr,
                                                              const uint32_t* entries);
 extern "C" __global__ void zxc_rle_expand_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, zxc_dev_pre_t* pre, uint8_t* rscratch,
-                                                 uint32_t* hdr, const uint32_t* entries_last);
+                                                 const uint32_t* hdr, const uint32_t* entries_last);
 #define ZXC_SECTIONS_KERNEL(name)                                                                                              \
     extern "C" __global__ void name(const uint8_t* comp, const zxc_dev_sec_t* secs, uint32_t* hdr, zxc_dev_pre_t* pre, uint8_t* pscratch)
 ZXC_SECTIONS_KERNEL(zxc_pivco_sections_small_kernel);
@@ -60,6 +60,9 @@ extern "C" __global__ void zxc_gather_blocks_kernel(const uint8_t* slots, uint32
 // Per-device scratch for expanded literal / token sections: one slot per resident
 // workgroup. Grown on demand, never shrunk; freed at process exit by the driver.
 #define ZXC_MAX_DEVICES 16
+#ifndef ZXC_RLE_LEAN_MAX_JOBS
+#define ZXC_RLE_LEAN_MAX_JOBS 16384u
+#endif
 #define ZXC_ORDER_STREAMS 8
 #define ZXC_POOLS 10 /* block_size_log2 12..21 */
 static struct {
@@ -154,6 +157,16 @@ int zxc_hip_memcpy_h2d_async(void* d_dst, const void* h_src, size_t bytes, void*
 int zxc_hip_memcpy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void* stream) {
     if (bytes == 0) return ZXC_OK;
     return hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
+}
+
+/* internal to the library (hidden): page-locked staging buffers of the host API's copy engine (zxc_host.c) */
+void* zxc_hip_host_alloc(size_t bytes) {
+    void* p = NULL;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return NULL;
+    return p;
+}
+void zxc_hip_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 extern "C" void zxc_host_release_arenas(void);
@@ -317,8 +330,12 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
             // The same way for the RLE scratch: hint[1] = 16-byte units the previous launch's LEAN_RLE candidates wanted (+ 1 per
             // workgroup that had any). None / first launch: no buffer, such blocks go to the full kernel as in round 3; else
             // a quarter more than last time (blocks that do not fit fall back to the full kernel one workgroup of 256 at a time).
-            if (two_pass && o.aux && o.hint) {
-                const uint32_t want16 = *(volatile uint32_t*)(o.hint + 1);
+            // Only for launches of fewer than ZXC_RLE_LEAN_MAX_JOBS blocks (the host API's batches, seekable ranges): these blocks
+            // are the heaviest of a level-3 archive, and in a short launch the one-wave full kernel's copy of the executor ends
+            // the launch with them (9 702 blocks: 1.25 -> 0.90 ms with this path); in a long one the full kernel beside the lean
+            // kernel is the faster arrangement (32 340 blocks: 2.25 vs 2.37 ms; 132 594: 8.75 vs 8.95 ms; profiles/r4b_rle_variants.log).
+            if (two_pass && o.aux && o.hint && n_jobs < ZXC_RLE_LEAN_MAX_JOBS) {
+                const uint32_t want16 = getenv("ZXC_MI355X_NO_RLE_SCRATCH") ? 0u : *(volatile uint32_t*)(o.hint + 1);  // (switch: A/B and fault isolation)
                 if (want16 != 0u) {
                     size_t need = ((size_t)want16 * 16u * 5u / 4u + 65536u) & ~(size_t)4095u;
                     const size_t most = (size_t)n_jobs * ((size_t)block_size + 96u);
@@ -373,7 +390,7 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
                            order, cap_override, (const uint8_t*)d_dict, dict_size, (const uint8_t*)d_dict_huf);
     else if (list) {
         // Streams forked from the caller's by an event and joined back into it (capturable, no host synchronisation).
-        //   no PRE blocks expected:  caller's: lean kernel over every block         | aux: full kernel over its list
+        //   no PRE blocks expected:  caller's: [RLE literals,] lean kernel over every block  | aux: full kernel over its list
         //   PRE blocks expected:     caller's: section kernels medium, large, [small done] | aux: lean kernel (LEAN class)
         //                            then the lean kernel's second entry (PRE blocks)     | aux2: section kernel small, THEN the full kernel
         // (the small class first: the lean kernel's second entry waits for small_done, and the full kernel's persistent
@@ -389,10 +406,11 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
             if (forked) { (void)hipStreamSynchronize(o.aux); (void)hipStreamSynchronize(o.aux2); }
             return ZXC_ERROR_GPU_UNAVAILABLE;
         };
-        auto launch_rle = [&](hipStream_t st) {  // the LEAN_RLE blocks' literals, in front of the lean kernel on its stream
-            if (rscratch_cap16)
-                hipLaunchKernelGGL(zxc_rle_expand_kernel, dim3(n_jobs < 8u * cus ? n_jobs : 8u * cus), dim3(64), 0, st, (const uint8_t*)d_comp, d_jobs,
-                                   pre, rscratch, ctl + ZXC_DEV_CTL_RLE_LIST, (const uint32_t*)(pre_entries + n_jobs - 1u));
+        // the LEAN_RLE blocks' literals, in front of the lean kernel on its stream (a small grid: it is over in a few microseconds)
+        auto launch_rle = [&](hipStream_t st) {
+            if (!rscratch_cap16) return;
+            hipLaunchKernelGGL(zxc_rle_expand_kernel, dim3(n_jobs < 8u * cus ? n_jobs : 8u * cus), dim3(64), 0, st, (const uint8_t*)d_comp, d_jobs, pre,
+                               rscratch, (const uint32_t*)(ctl + ZXC_DEV_CTL_RLE_LIST), (const uint32_t*)(pre_entries + n_jobs - 1u));
         };
         auto launch_full = [&]() {
 #ifndef EXP_SKIP_FULL  // (experiment: the lean kernel's own time; the other blocks stay undecoded)

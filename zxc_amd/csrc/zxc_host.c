@@ -309,6 +309,130 @@ static void* arena_reserve(arena_t* a, int which, size_t need) {
     }
     return d->p;
 }
+/* ------------------------------------------------------------ copy engine: pageable host memory <-> device
+ * The buffers of zxc_decompress / zxc_compress / the seekable API are ordinary (pageable) host memory. One hipMemcpy of such a
+ * buffer is staged by the runtime through its own pinned buffer by ONE thread (~25 GB/s measured on the bench box,
+ * profiles/r2u_hostbench.log: "C call only 26 GB/s"), well under the link. Here a large copy is cut into XFER_CHUNK pieces
+ * dealt round-robin to XFER_LANES worker threads; every lane owns two page-locked staging buffers and two streams and
+ * double-buffers: the DMA of piece k+1 runs while the lane memcpy()s piece k between staging and the caller's buffer
+ * ("pinned double-buffered staging"). The engine is a per-device singleton (one big copy at a
+ * time; a second caller falls back to the plain copy), its 64 MiB of staging is kept until zxc_mi355x_release_cached(). */
+void* zxc_hip_host_alloc(size_t bytes);
+void zxc_hip_host_free(void* p);
+#define XFER_LANES 4
+#define XFER_CHUNK ((size_t)8 << 20)
+#define XFER_MIN ((size_t)16 << 20)
+typedef struct {
+    pthread_mutex_t mu;
+    int ready;
+    void* pinned[XFER_LANES][2];
+    void* stream[XFER_LANES][2];
+} xfer_engine_t;
+static xfer_engine_t g_xfer[HOST_MAX_DEVICES];
+static pthread_once_t g_xfer_once = PTHREAD_ONCE_INIT;
+static void xfer_init_all(void) {
+    for (int i = 0; i < HOST_MAX_DEVICES; i++) pthread_mutex_init(&g_xfer[i].mu, NULL);
+}
+static void xfer_destroy(xfer_engine_t* e) { /* (the caller holds e->mu and is on the engine's device) */
+    for (int l = 0; l < XFER_LANES; l++)
+        for (int k = 0; k < 2; k++) {
+            zxc_hip_host_free(e->pinned[l][k]);
+            zxc_hip_stream_destroy(e->stream[l][k]);
+            e->pinned[l][k] = NULL;
+            e->stream[l][k] = NULL;
+        }
+    e->ready = 0;
+}
+static int xfer_prepare(xfer_engine_t* e) {
+    if (e->ready) return 1;
+    for (int l = 0; l < XFER_LANES; l++)
+        for (int k = 0; k < 2; k++) {
+            e->pinned[l][k] = zxc_hip_host_alloc(XFER_CHUNK);
+            if (!e->pinned[l][k] || zxc_hip_stream_create(&e->stream[l][k]) != ZXC_OK) { xfer_destroy(e); return 0; }
+        }
+    e->ready = 1;
+    return 1;
+}
+typedef struct {
+    xfer_engine_t* e;
+    int lane, device, to_device, rc;
+    uint8_t* host;
+    uint8_t* dev;
+    size_t bytes;
+} xfer_job_t;
+static void* xfer_lane_main(void* arg) {
+    xfer_job_t* j = (xfer_job_t*)arg;
+    xfer_engine_t* e = j->e;
+    const int l = j->lane;
+    j->rc = zxc_mi355x_set_device(j->device);
+    if (j->rc != ZXC_OK) return NULL;
+    const size_t n_chunks = (j->bytes + XFER_CHUNK - 1) / XFER_CHUNK;
+    size_t prev_off = 0, prev_len = 0;
+    int k = 0, have_prev = 0;
+    for (size_t c = (size_t)l; c < n_chunks && j->rc == ZXC_OK; c += XFER_LANES, k ^= 1) {
+        const size_t off = c * XFER_CHUNK, len = j->bytes - off < XFER_CHUNK ? j->bytes - off : XFER_CHUNK;
+        if (j->to_device) {
+            /* staging buffer k was last used two pieces ago: its DMA must have left before it is overwritten */
+            j->rc = zxc_mi355x_synchronize(e->stream[l][k]);
+            if (j->rc != ZXC_OK) break;
+            memcpy(e->pinned[l][k], j->host + off, len);
+            j->rc = zxc_hip_memcpy_h2d_async(j->dev + off, e->pinned[l][k], len, e->stream[l][k]);
+        } else {
+            j->rc = zxc_hip_memcpy_d2h_async(e->pinned[l][k], j->dev + off, len, e->stream[l][k]);
+            if (have_prev && j->rc == ZXC_OK) { /* the piece before this one, from the other staging buffer, while this DMA runs */
+                j->rc = zxc_mi355x_synchronize(e->stream[l][k ^ 1]);
+                if (j->rc == ZXC_OK) memcpy(j->host + prev_off, e->pinned[l][k ^ 1], prev_len);
+            }
+            prev_off = off;
+            prev_len = len;
+            have_prev = 1;
+        }
+    }
+    if (j->to_device) {
+        for (int q = 0; q < 2; q++) { const int r = zxc_mi355x_synchronize(e->stream[l][q]); if (j->rc == ZXC_OK) j->rc = r; }
+    } else if (have_prev) {
+        const int r = zxc_mi355x_synchronize(e->stream[l][k ^ 1]);
+        if (j->rc == ZXC_OK) j->rc = r;
+        if (j->rc == ZXC_OK) memcpy(j->host + prev_off, e->pinned[l][k ^ 1], prev_len);
+        (void)zxc_mi355x_synchronize(e->stream[l][k]);
+    }
+    return NULL;
+}
+/* One large copy between pageable host memory and the device, complete when this returns. `after` (or NULL): a stream whose
+ * earlier work (the launch that produced d) must be finished first / whose later work may rely on the copy (host-ordered:
+ * the call synchronises). Falls back to a plain copy for small sizes, a busy engine or a failed set-up. */
+static int xfer_copy(int to_device, void* dev_ptr, void* host_ptr, size_t bytes, void* after) {
+    if (bytes == 0) return ZXC_OK;
+    const int device = zxc_hip_current_device();
+    if (after) { const int rc = zxc_mi355x_synchronize(after); if (rc != ZXC_OK) return rc; }
+    xfer_engine_t* e = NULL;
+    if (bytes >= XFER_MIN && device >= 0 && device < HOST_MAX_DEVICES && !getenv("ZXC_MI355X_PLAIN_COPIES")) {
+        pthread_once(&g_xfer_once, xfer_init_all);
+        e = &g_xfer[device];
+        if (pthread_mutex_trylock(&e->mu) != 0) e = NULL;
+        else if (!xfer_prepare(e)) { pthread_mutex_unlock(&e->mu); e = NULL; }
+    }
+    if (!e) return to_device ? zxc_mi355x_memcpy_h2d(dev_ptr, host_ptr, bytes) : zxc_mi355x_memcpy_d2h(host_ptr, dev_ptr, bytes);
+    xfer_job_t job[XFER_LANES];
+    pthread_t th[XFER_LANES];
+    int live[XFER_LANES];
+    for (int l = 0; l < XFER_LANES; l++) {
+        job[l] = (xfer_job_t){e, l, device, to_device, ZXC_OK, (uint8_t*)host_ptr, (uint8_t*)dev_ptr, bytes};
+        live[l] = l == 0 ? 0 : pthread_create(&th[l], NULL, xfer_lane_main, &job[l]) == 0;
+    }
+    xfer_lane_main(&job[0]); /* the caller is lane 0 */
+    int rc = job[0].rc;
+    for (int l = 1; l < XFER_LANES; l++) {
+        if (live[l]) pthread_join(th[l], NULL);
+        else xfer_lane_main(&job[l]); /* (no thread: the caller does that lane's pieces too) */
+        if (rc == ZXC_OK) rc = job[l].rc;
+    }
+    pthread_mutex_unlock(&e->mu);
+    return rc;
+}
+static int xfer_h2d(void* d_dst, const void* h_src, size_t bytes, void* after) { return xfer_copy(1, d_dst, (void*)(uintptr_t)h_src, bytes, after); }
+static int xfer_d2h(void* h_dst, const void* d_src, size_t bytes, void* after) { return xfer_copy(0, (void*)(uintptr_t)d_src, h_dst, bytes, after); }
+
 /* internal to the library (called by zxc_mi355x_release_cached in the shim): free every arena nobody holds */
 void zxc_host_release_arenas(void) {
     pthread_once(&g_arena_once, arena_init_all);
@@ -323,6 +447,13 @@ void zxc_host_release_arenas(void) {
                 for (int w = 0; w < AR_N; w++) { zxc_mi355x_free(a->buf[w].p); a->buf[w].p = NULL; a->buf[w].cap = 0; }
             pthread_mutex_unlock(&a->mu);
         }
+    pthread_once(&g_xfer_once, xfer_init_all);
+    for (int dev = 0; dev < HOST_MAX_DEVICES; dev++) { /* the copy engines' staging */
+        xfer_engine_t* e = &g_xfer[dev];
+        if (pthread_mutex_trylock(&e->mu) != 0) continue;
+        if (e->ready && zxc_mi355x_set_device(dev) == ZXC_OK) xfer_destroy(e);
+        pthread_mutex_unlock(&e->mu);
+    }
     if (cur >= 0) (void)zxc_mi355x_set_device(cur);
 }
 
@@ -357,9 +488,7 @@ static void dev_bufs_free(dev_bufs_t* b) {
 /* decoded bytes of the batch back to the host, on the batch's stream */
 static int dev_bufs_read(const dev_bufs_t* b, void* h_dst, size_t d_off, size_t bytes) {
     if (bytes == 0) return ZXC_OK;
-    if (!b->stream) return zxc_mi355x_memcpy_d2h(h_dst, (const uint8_t*)b->d_out + d_off, bytes);
-    const int rc = zxc_hip_memcpy_d2h_async(h_dst, (const uint8_t*)b->d_out + d_off, bytes, b->stream);
-    return rc == ZXC_OK ? zxc_mi355x_synchronize(b->stream) : rc;
+    return xfer_d2h(h_dst, (const uint8_t*)b->d_out + d_off, bytes, b->stream);
 }
 
 static int run_jobs_on(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_job_t* jobs, uint32_t n,
@@ -381,7 +510,7 @@ static int run_jobs_on(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_j
     b->d_status = arena_reserve(a, AR_STATUS, (size_t)n * sizeof(int32_t));
     int rc = ZXC_ERROR_MEMORY;
     if (b->d_comp && b->d_jobs && b->d_out && b->d_status) {
-        rc = stream ? zxc_hip_memcpy_h2d_async(b->d_comp, h_comp, comp_bytes, stream) : zxc_mi355x_memcpy_h2d(b->d_comp, h_comp, comp_bytes);
+        rc = xfer_h2d(b->d_comp, h_comp, comp_bytes, NULL); /* (complete on return: the launch below is enqueued after it) */
         if (rc == ZXC_OK)
             rc = stream ? zxc_hip_memcpy_h2d_async(b->d_jobs, jobs, (size_t)n * sizeof(zxc_dev_job_t), stream)
                         : zxc_mi355x_memcpy_h2d(b->d_jobs, jobs, (size_t)n * sizeof(zxc_dev_job_t));
@@ -527,7 +656,7 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
             }
             if (rc != ZXC_OK) ret = rc;
         } else if (ret == 0) {
-            const int crc = zxc_mi355x_memcpy_d2h(dst + total, b.d_out, batch_total);
+            const int crc = xfer_d2h(dst + total, b.d_out, batch_total, NULL);
             if (crc != ZXC_OK) ret = crc;
         }
         (void)good;
@@ -650,7 +779,7 @@ int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const 
         void* d_work = dict_size ? zxc_mi355x_malloc((size_t)zxc_mi355x_encode_dict_work_size(src_size, (uint32_t)block_size, (uint32_t)dict_size)) : NULL;
         int64_t rc = ZXC_ERROR_MEMORY;
         if (sizes && offs && d_src && d_slots && d_sizes && d_offs && (!dict_size || (d_dict && d_work))) {
-            rc = zxc_mi355x_memcpy_h2d(d_src, src, src_size);
+            rc = xfer_h2d(d_src, src, src_size, NULL);
             if (rc == ZXC_OK && dict_size) rc = zxc_mi355x_memcpy_h2d(d_dict, dict, dict_size);
             if (rc == ZXC_OK)
                 rc = dict_size ? zxc_mi355x_encode_blocks_dict_device(d_src, src_size, (uint32_t)block_size, level, checksum_enabled,
@@ -674,7 +803,7 @@ int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const 
                 rc = zxc_mi355x_gather_blocks_device(d_slots, (uint32_t)block_size, (const uint32_t*)d_sizes,
                                                      (const uint64_t*)d_offs, d_out, nb, NULL);
             if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(NULL);
-            if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(dst + op, d_out, (size_t)total);
+            if (rc == ZXC_OK) rc = xfer_d2h(dst + op, d_out, (size_t)total, NULL);
             if (rc == ZXC_OK && checksum_enabled) /* fold the block trailers in stream order (zxc_dispatch.c:754-759) */
                 for (uint32_t i = 0; i < nb; i++)
                     global_hash = ((global_hash << 1) | (global_hash >> 31)) ^ rd32(dst + op + offs[i] + sizes[i] - 4);
