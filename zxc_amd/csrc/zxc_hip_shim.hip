@@ -159,16 +159,6 @@ int zxc_hip_memcpy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void*
     return hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
 }
 
-/* internal to the library (hidden): page-locked staging buffers of the host API's copy engine (zxc_host.c) */
-void* zxc_hip_host_alloc(size_t bytes) {
-    void* p = NULL;
-    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return NULL;
-    return p;
-}
-void zxc_hip_host_free(void* p) {
-    if (p) (void)hipHostFree(p);
-}
-
 extern "C" void zxc_host_release_arenas(void);
 /* Gives back the device memory this library keeps between calls: the host API's staging arenas (those nobody is using)
  * and, on the calling thread's device, the scratch pools of the section decoders and the launch-order buffers. Call it

@@ -25,6 +25,7 @@
 #define BLK_HDR 8
 #define TAIL_PAD 2112u /* ZXC_DECOMPRESS_TAIL_PAD, src/lib/zxc_internal.h:341 */
 #define HOST_BATCH_BYTES ((size_t)256 << 20) /* output slots per launch of the host Buffer API */
+#define FRAME_BATCH_BYTES ((size_t)128 << 20) /* zxc_decompress: two batches in flight (upload + launch of one beside the download of the other) */
 enum { BLK_RAW = 0, BLK_GLO = 1, BLK_GHI = 2, BLK_SEK = 254, BLK_EOF = 255 };
 
 static uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
@@ -309,130 +310,6 @@ static void* arena_reserve(arena_t* a, int which, size_t need) {
     }
     return d->p;
 }
-/* ------------------------------------------------------------ copy engine: pageable host memory <-> device
- * The buffers of zxc_decompress / zxc_compress / the seekable API are ordinary (pageable) host memory. One hipMemcpy of such a
- * buffer is staged by the runtime through its own pinned buffer by ONE thread (~25 GB/s measured on the bench box,
- * profiles/r2u_hostbench.log: "C call only 26 GB/s"), well under the link. Here a large copy is cut into XFER_CHUNK pieces
- * dealt round-robin to XFER_LANES worker threads; every lane owns two page-locked staging buffers and two streams and
- * double-buffers: the DMA of piece k+1 runs while the lane memcpy()s piece k between staging and the caller's buffer
- * ("pinned double-buffered staging"). The engine is a per-device singleton (one big copy at a
- * time; a second caller falls back to the plain copy), its 64 MiB of staging is kept until zxc_mi355x_release_cached(). */
-void* zxc_hip_host_alloc(size_t bytes);
-void zxc_hip_host_free(void* p);
-#define XFER_LANES 4
-#define XFER_CHUNK ((size_t)8 << 20)
-#define XFER_MIN ((size_t)16 << 20)
-typedef struct {
-    pthread_mutex_t mu;
-    int ready;
-    void* pinned[XFER_LANES][2];
-    void* stream[XFER_LANES][2];
-} xfer_engine_t;
-static xfer_engine_t g_xfer[HOST_MAX_DEVICES];
-static pthread_once_t g_xfer_once = PTHREAD_ONCE_INIT;
-static void xfer_init_all(void) {
-    for (int i = 0; i < HOST_MAX_DEVICES; i++) pthread_mutex_init(&g_xfer[i].mu, NULL);
-}
-static void xfer_destroy(xfer_engine_t* e) { /* (the caller holds e->mu and is on the engine's device) */
-    for (int l = 0; l < XFER_LANES; l++)
-        for (int k = 0; k < 2; k++) {
-            zxc_hip_host_free(e->pinned[l][k]);
-            zxc_hip_stream_destroy(e->stream[l][k]);
-            e->pinned[l][k] = NULL;
-            e->stream[l][k] = NULL;
-        }
-    e->ready = 0;
-}
-static int xfer_prepare(xfer_engine_t* e) {
-    if (e->ready) return 1;
-    for (int l = 0; l < XFER_LANES; l++)
-        for (int k = 0; k < 2; k++) {
-            e->pinned[l][k] = zxc_hip_host_alloc(XFER_CHUNK);
-            if (!e->pinned[l][k] || zxc_hip_stream_create(&e->stream[l][k]) != ZXC_OK) { xfer_destroy(e); return 0; }
-        }
-    e->ready = 1;
-    return 1;
-}
-typedef struct {
-    xfer_engine_t* e;
-    int lane, device, to_device, rc;
-    uint8_t* host;
-    uint8_t* dev;
-    size_t bytes;
-} xfer_job_t;
-static void* xfer_lane_main(void* arg) {
-    xfer_job_t* j = (xfer_job_t*)arg;
-    xfer_engine_t* e = j->e;
-    const int l = j->lane;
-    j->rc = zxc_mi355x_set_device(j->device);
-    if (j->rc != ZXC_OK) return NULL;
-    const size_t n_chunks = (j->bytes + XFER_CHUNK - 1) / XFER_CHUNK;
-    size_t prev_off = 0, prev_len = 0;
-    int k = 0, have_prev = 0;
-    for (size_t c = (size_t)l; c < n_chunks && j->rc == ZXC_OK; c += XFER_LANES, k ^= 1) {
-        const size_t off = c * XFER_CHUNK, len = j->bytes - off < XFER_CHUNK ? j->bytes - off : XFER_CHUNK;
-        if (j->to_device) {
-            /* staging buffer k was last used two pieces ago: its DMA must have left before it is overwritten */
-            j->rc = zxc_mi355x_synchronize(e->stream[l][k]);
-            if (j->rc != ZXC_OK) break;
-            memcpy(e->pinned[l][k], j->host + off, len);
-            j->rc = zxc_hip_memcpy_h2d_async(j->dev + off, e->pinned[l][k], len, e->stream[l][k]);
-        } else {
-            j->rc = zxc_hip_memcpy_d2h_async(e->pinned[l][k], j->dev + off, len, e->stream[l][k]);
-            if (have_prev && j->rc == ZXC_OK) { /* the piece before this one, from the other staging buffer, while this DMA runs */
-                j->rc = zxc_mi355x_synchronize(e->stream[l][k ^ 1]);
-                if (j->rc == ZXC_OK) memcpy(j->host + prev_off, e->pinned[l][k ^ 1], prev_len);
-            }
-            prev_off = off;
-            prev_len = len;
-            have_prev = 1;
-        }
-    }
-    if (j->to_device) {
-        for (int q = 0; q < 2; q++) { const int r = zxc_mi355x_synchronize(e->stream[l][q]); if (j->rc == ZXC_OK) j->rc = r; }
-    } else if (have_prev) {
-        const int r = zxc_mi355x_synchronize(e->stream[l][k ^ 1]);
-        if (j->rc == ZXC_OK) j->rc = r;
-        if (j->rc == ZXC_OK) memcpy(j->host + prev_off, e->pinned[l][k ^ 1], prev_len);
-        (void)zxc_mi355x_synchronize(e->stream[l][k]);
-    }
-    return NULL;
-}
-/* One large copy between pageable host memory and the device, complete when this returns. `after` (or NULL): a stream whose
- * earlier work (the launch that produced d) must be finished first / whose later work may rely on the copy (host-ordered:
- * the call synchronises). Falls back to a plain copy for small sizes, a busy engine or a failed set-up. */
-static int xfer_copy(int to_device, void* dev_ptr, void* host_ptr, size_t bytes, void* after) {
-    if (bytes == 0) return ZXC_OK;
-    const int device = zxc_hip_current_device();
-    if (after) { const int rc = zxc_mi355x_synchronize(after); if (rc != ZXC_OK) return rc; }
-    xfer_engine_t* e = NULL;
-    if (bytes >= XFER_MIN && device >= 0 && device < HOST_MAX_DEVICES && !getenv("ZXC_MI355X_PLAIN_COPIES")) {
-        pthread_once(&g_xfer_once, xfer_init_all);
-        e = &g_xfer[device];
-        if (pthread_mutex_trylock(&e->mu) != 0) e = NULL;
-        else if (!xfer_prepare(e)) { pthread_mutex_unlock(&e->mu); e = NULL; }
-    }
-    if (!e) return to_device ? zxc_mi355x_memcpy_h2d(dev_ptr, host_ptr, bytes) : zxc_mi355x_memcpy_d2h(host_ptr, dev_ptr, bytes);
-    xfer_job_t job[XFER_LANES];
-    pthread_t th[XFER_LANES];
-    int live[XFER_LANES];
-    for (int l = 0; l < XFER_LANES; l++) {
-        job[l] = (xfer_job_t){e, l, device, to_device, ZXC_OK, (uint8_t*)host_ptr, (uint8_t*)dev_ptr, bytes};
-        live[l] = l == 0 ? 0 : pthread_create(&th[l], NULL, xfer_lane_main, &job[l]) == 0;
-    }
-    xfer_lane_main(&job[0]); /* the caller is lane 0 */
-    int rc = job[0].rc;
-    for (int l = 1; l < XFER_LANES; l++) {
-        if (live[l]) pthread_join(th[l], NULL);
-        else xfer_lane_main(&job[l]); /* (no thread: the caller does that lane's pieces too) */
-        if (rc == ZXC_OK) rc = job[l].rc;
-    }
-    pthread_mutex_unlock(&e->mu);
-    return rc;
-}
-static int xfer_h2d(void* d_dst, const void* h_src, size_t bytes, void* after) { return xfer_copy(1, d_dst, (void*)(uintptr_t)h_src, bytes, after); }
-static int xfer_d2h(void* h_dst, const void* d_src, size_t bytes, void* after) { return xfer_copy(0, (void*)(uintptr_t)d_src, h_dst, bytes, after); }
-
 /* internal to the library (called by zxc_mi355x_release_cached in the shim): free every arena nobody holds */
 void zxc_host_release_arenas(void) {
     pthread_once(&g_arena_once, arena_init_all);
@@ -447,13 +324,6 @@ void zxc_host_release_arenas(void) {
                 for (int w = 0; w < AR_N; w++) { zxc_mi355x_free(a->buf[w].p); a->buf[w].p = NULL; a->buf[w].cap = 0; }
             pthread_mutex_unlock(&a->mu);
         }
-    pthread_once(&g_xfer_once, xfer_init_all);
-    for (int dev = 0; dev < HOST_MAX_DEVICES; dev++) { /* the copy engines' staging */
-        xfer_engine_t* e = &g_xfer[dev];
-        if (pthread_mutex_trylock(&e->mu) != 0) continue;
-        if (e->ready && zxc_mi355x_set_device(dev) == ZXC_OK) xfer_destroy(e);
-        pthread_mutex_unlock(&e->mu);
-    }
     if (cur >= 0) (void)zxc_mi355x_set_device(cur);
 }
 
@@ -488,19 +358,27 @@ static void dev_bufs_free(dev_bufs_t* b) {
 /* decoded bytes of the batch back to the host, on the batch's stream */
 static int dev_bufs_read(const dev_bufs_t* b, void* h_dst, size_t d_off, size_t bytes) {
     if (bytes == 0) return ZXC_OK;
-    return xfer_d2h(h_dst, (const uint8_t*)b->d_out + d_off, bytes, b->stream);
+    if (!b->stream) return zxc_mi355x_memcpy_d2h(h_dst, (const uint8_t*)b->d_out + d_off, bytes);
+    const int rc = zxc_hip_memcpy_d2h_async(h_dst, (const uint8_t*)b->d_out + d_off, bytes, b->stream);
+    return rc == ZXC_OK ? zxc_mi355x_synchronize(b->stream) : rc;
 }
 
-static int run_jobs_on(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_job_t* jobs, uint32_t n,
-                       size_t out_bytes, uint32_t block_size, uint32_t cap_override, int verify_trailer,
-                       int32_t* h_status, dev_bufs_t* b, const dict_ref_t* dr, int sub, void* stream) {
+/* Stage 1 of a batch: take the arena (dev, sub), reserve its buffers and upload the compressed bytes, the job table and the
+ * dictionary. `stream` NULL: plain (synchronous) copies; else copies on that stream, complete when this returns. On failure the
+ * arena is released. The two stages are separate so that zxc_decompress can upload batch i+1 from a helper thread while batch i's
+ * output goes back to the host (PCIe is full duplex; one direction at a time left a third of the link idle). */
+static int jobs_upload(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_job_t* jobs, uint32_t n, size_t out_bytes,
+                       dev_bufs_t* b, const dict_ref_t* dr, int sub, void* stream, arena_t* locked) {
+    /* `locked`: the arena to use, already locked by the thread that will release it (a mutex is released by the thread that took
+     * it: zxc_decompress takes the helper's arena itself); a failure then leaves the release to that caller too */
     memset(b, 0, sizeof(*b));
+    b->held = locked;
     if (zxc_mi355x_device_count() <= 0) return ZXC_ERROR_GPU_UNAVAILABLE;
     const int dev = zxc_hip_current_device();
     if (dev < 0 || dev >= HOST_MAX_DEVICES || sub < 0 || sub >= ARENA_SUBS) return ZXC_ERROR_GPU_UNAVAILABLE;
     pthread_once(&g_arena_once, arena_init_all);
-    arena_t* a = &g_arena[dev][sub];
-    pthread_mutex_lock(&a->mu);
+    arena_t* a = locked ? locked : &g_arena[dev][sub];
+    if (!locked) pthread_mutex_lock(&a->mu);
     b->held = a;
     b->stream = stream;
     /* +64: the kernel's 16-byte literal / extras reads may run past the last block */
@@ -510,33 +388,45 @@ static int run_jobs_on(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_j
     b->d_status = arena_reserve(a, AR_STATUS, (size_t)n * sizeof(int32_t));
     int rc = ZXC_ERROR_MEMORY;
     if (b->d_comp && b->d_jobs && b->d_out && b->d_status) {
-        rc = xfer_h2d(b->d_comp, h_comp, comp_bytes, NULL); /* (complete on return: the launch below is enqueued after it) */
+        rc = stream ? zxc_hip_memcpy_h2d_async(b->d_comp, h_comp, comp_bytes, stream) : zxc_mi355x_memcpy_h2d(b->d_comp, h_comp, comp_bytes);
         if (rc == ZXC_OK)
             rc = stream ? zxc_hip_memcpy_h2d_async(b->d_jobs, jobs, (size_t)n * sizeof(zxc_dev_job_t), stream)
                         : zxc_mi355x_memcpy_h2d(b->d_jobs, jobs, (size_t)n * sizeof(zxc_dev_job_t));
+        if (rc == ZXC_OK && stream) rc = zxc_mi355x_synchronize(stream);
         if (rc == ZXC_OK && dr && dr->dict_size) {
             b->d_dict = arena_reserve(a, AR_DICT, dr->dict_size + ZXC_HUF_TABLE_SIZE + 64);
             if (!b->d_dict) rc = ZXC_ERROR_MEMORY;
-            if (rc == ZXC_OK && stream) rc = zxc_mi355x_synchronize(stream); /* (the dictionary goes up with plain copies) */
-            if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_h2d(b->d_dict, dr->dict, dr->dict_size);
+            if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_h2d(b->d_dict, dr->dict, dr->dict_size); /* (the dictionary goes up with plain copies) */
             if (rc == ZXC_OK && dr->dict_huf)
                 rc = zxc_mi355x_memcpy_h2d((uint8_t*)b->d_dict + dr->dict_size, dr->dict_huf, ZXC_HUF_TABLE_SIZE);
         }
-        if (rc == ZXC_OK)
-            rc = zxc_hip_decode_blocks(b->d_comp, (const zxc_dev_job_t*)b->d_jobs, n, b->d_out, (int32_t*)b->d_status,
-                                       block_size, verify_trailer, b->d_dict, b->d_dict ? (uint32_t)dr->dict_size : 0u,
-                                       (b->d_dict && dr->dict_huf) ? (uint8_t*)b->d_dict + dr->dict_size : NULL,
-                                       cap_override, stream);
-        if (rc == ZXC_OK && stream) {
-            rc = zxc_hip_memcpy_d2h_async(h_status, b->d_status, (size_t)n * sizeof(int32_t), stream);
-            if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(stream);
-        } else if (rc == ZXC_OK) {
-            rc = zxc_mi355x_synchronize(NULL);
-            if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(h_status, b->d_status, (size_t)n * sizeof(int32_t));
-        }
+    }
+    if (rc != ZXC_OK && !locked) dev_bufs_free(b);
+    return rc;
+}
+/* Stage 2: the launch over an uploaded batch and its statuses back on the host (synchronises). */
+static int jobs_execute(dev_bufs_t* b, uint32_t n, uint32_t block_size, uint32_t cap_override, int verify_trailer,
+                        int32_t* h_status, const dict_ref_t* dr, void* stream) {
+    b->stream = stream;
+    int rc = zxc_hip_decode_blocks(b->d_comp, (const zxc_dev_job_t*)b->d_jobs, n, b->d_out, (int32_t*)b->d_status,
+                                   block_size, verify_trailer, b->d_dict, b->d_dict ? (uint32_t)dr->dict_size : 0u,
+                                   (b->d_dict && dr->dict_huf) ? (uint8_t*)b->d_dict + dr->dict_size : NULL,
+                                   cap_override, stream);
+    if (rc == ZXC_OK && stream) {
+        rc = zxc_hip_memcpy_d2h_async(h_status, b->d_status, (size_t)n * sizeof(int32_t), stream);
+        if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(stream);
+    } else if (rc == ZXC_OK) {
+        rc = zxc_mi355x_synchronize(NULL);
+        if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(h_status, b->d_status, (size_t)n * sizeof(int32_t));
     }
     if (rc != ZXC_OK) dev_bufs_free(b);
     return rc;
+}
+static int run_jobs_on(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_job_t* jobs, uint32_t n,
+                       size_t out_bytes, uint32_t block_size, uint32_t cap_override, int verify_trailer,
+                       int32_t* h_status, dev_bufs_t* b, const dict_ref_t* dr, int sub, void* stream) {
+    const int rc = jobs_upload(h_comp, comp_bytes, jobs, n, out_bytes, b, dr, sub, stream, NULL);
+    return rc == ZXC_OK ? jobs_execute(b, n, block_size, cap_override, verify_trailer, h_status, dr, stream) : rc;
 }
 
 static int run_jobs_cap(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_job_t* jobs, uint32_t n,
@@ -552,6 +442,34 @@ static int run_jobs(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_job_
 }
 
 /* ------------------------------------------------------------ zxc_decompress */
+typedef struct {
+    const uint8_t* h_comp;
+    size_t comp_bytes;
+    const zxc_dev_job_t* jobs;
+    uint32_t n;
+    size_t out_bytes;
+    dev_bufs_t* b;
+    const dict_ref_t* dr;
+    int sub;
+    void* stream;
+    arena_t* arena; /* locked by the thread that started the helper */
+    int device, rc;
+    uint32_t block_size; /* the launch over the uploaded batch, on the helper's stream, and its statuses */
+    int verify;
+    int32_t* st;
+} host_upload_t;
+static void* host_upload_main(void* arg) {
+    host_upload_t* u = (host_upload_t*)arg;
+    u->rc = zxc_mi355x_set_device(u->device);
+    if (u->rc == ZXC_OK) u->rc = jobs_upload(u->h_comp, u->comp_bytes, u->jobs, u->n, u->out_bytes, u->b, u->dr, u->sub, u->stream, u->arena);
+    if (u->rc == ZXC_OK) { /* (jobs_execute releases the arena when it fails: not ours to release here — keep the handle for the caller) */
+        dev_bufs_t tmp = *u->b;
+        tmp.held = NULL;
+        u->rc = jobs_execute(&tmp, u->n, u->block_size, 0u, u->verify, u->st, u->dr, u->stream);
+    }
+    return NULL;
+}
+
 int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, const size_t dst_capacity,
                        const zxc_decompress_opts_t* opts) {
     const uint8_t* src = (const uint8_t*)src_v;
@@ -582,11 +500,22 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
      * of the untrusted block count, and decoding stops at the first failing or overflowing block like
      * the reference's sequential loop (zxc_dispatch.c:912-1001). A problem found at block k is only
      * reported if blocks 0..k-1 all decode (first failure in stream order wins). */
-    uint32_t batch_blocks = (uint32_t)(HOST_BATCH_BYTES / block_size);
+    size_t batch_bytes = FRAME_BATCH_BYTES;
+    { const char* e = getenv("ZXC_MI355X_FRAME_BATCH_MIB"); if (e && atoi(e) >= 1 && atoi(e) <= 1024) batch_bytes = (size_t)atoi(e) << 20; }
+    uint32_t batch_blocks = (uint32_t)(batch_bytes / block_size);
     if (batch_blocks < 16u) batch_blocks = 16u;
-    zxc_dev_job_t* jobs = (zxc_dev_job_t*)malloc((size_t)batch_blocks * sizeof(*jobs));
-    int32_t* st = (int32_t*)malloc((size_t)batch_blocks * sizeof(int32_t));
-    if (!jobs || !st) { free(jobs); free(st); return ZXC_ERROR_MEMORY; }
+    /* Two batches in flight: while batch i's decoded bytes go back to the host on this thread, a helper thread uploads batch
+     * i+1 (its own arena, its own stream) — the link carries both directions at once. W[k]: the walked batch in slot k. */
+    struct { zxc_dev_job_t* jobs; int32_t* st; uint32_t n; size_t span0, span; int last, uploaded; dev_bufs_t b; } W[2];
+    memset(W, 0, sizeof W);
+    for (int k = 0; k < 2; k++) {
+        W[k].jobs = (zxc_dev_job_t*)malloc((size_t)batch_blocks * sizeof(zxc_dev_job_t));
+        W[k].st = (int32_t*)malloc((size_t)batch_blocks * sizeof(int32_t));
+    }
+    if (!W[0].jobs || !W[1].jobs || !W[0].st || !W[1].st) {
+        for (int k = 0; k < 2; k++) { free(W[k].jobs); free(W[k].st); }
+        return ZXC_ERROR_MEMORY;
+    }
     size_t ip = ZXC_FILE_HEADER_SIZE;
     int tail_err = 0;         /* error to report after all queued blocks succeed */
     uint32_t global_hash = 0; /* rotl1-xor fold of the stored per-block checksums (zxc_internal.h:1390-1393) */
@@ -594,58 +523,119 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
     int64_t ret = 0;
     size_t total = 0;
     const uint32_t slot = (block_size + TAIL_PAD + 15u) & ~15u;
-    while (!done && ret == 0) {
-        uint32_t n = 0;
-        const size_t span0 = ip;
-        while (n < batch_blocks) {
-            if (ip >= src_size) { done = 1; break; }
-            const size_t rem = src_size - ip;
-            uint8_t type;
-            uint32_t csz;
-            if (read_block_header(src + ip, rem, &type, &csz) != ZXC_OK) { tail_err = ZXC_ERROR_BAD_HEADER; done = 1; break; }
-            if (type == BLK_EOF) {
-                if (csz != 0) tail_err = ZXC_ERROR_BAD_HEADER;
-                saw_eof = 1;
-                done = 1;
-                break;
-            }
-            const uint64_t phys = (uint64_t)BLK_HDR + csz + (file_ck ? 4u : 0u);
-            jobs[n].comp_off = ip - span0;
-            /* the wrapper sees "all remaining bytes"; any size >= the physical block is equivalent */
-            { const uint64_t cs = phys < rem ? phys : rem; jobs[n].comp_size = cs > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cs; }
-            jobs[n].out_off = (uint64_t)n * block_size;
-            jobs[n].out_len = block_size;
-            n++;
-            if (verify && phys <= rem)
-                global_hash = ((global_hash << 1) | (global_hash >> 31)) ^ rd32(src + ip + BLK_HDR + csz);
-            if (phys >= rem) { ip = src_size; done = 1; break; }
-            ip += (size_t)phys;
-        }
-        if (n == 0) break;
-        const size_t span = ip - span0;
+    void* up_stream = NULL;   /* the helper's stream, created with the first second batch */
+    /* the 8-byte block headers of the next batch -> W[k] (host only) */
+#define WALK_BATCH(k)                                                                                                      \
+    do {                                                                                                                   \
+        zxc_dev_job_t* jobs = W[k].jobs;                                                                                   \
+        uint32_t n = 0;                                                                                                    \
+        const size_t span0 = ip;                                                                                           \
+        while (!done && n < batch_blocks) {                                                                                \
+            if (ip >= src_size) { done = 1; break; }                                                                       \
+            const size_t rem = src_size - ip;                                                                              \
+            uint8_t type;                                                                                                  \
+            uint32_t csz;                                                                                                  \
+            if (read_block_header(src + ip, rem, &type, &csz) != ZXC_OK) { tail_err = ZXC_ERROR_BAD_HEADER; done = 1; break; } \
+            if (type == BLK_EOF) {                                                                                         \
+                if (csz != 0) tail_err = ZXC_ERROR_BAD_HEADER;                                                             \
+                saw_eof = 1;                                                                                               \
+                done = 1;                                                                                                  \
+                break;                                                                                                     \
+            }                                                                                                              \
+            const uint64_t phys = (uint64_t)BLK_HDR + csz + (file_ck ? 4u : 0u);                                           \
+            jobs[n].comp_off = ip - span0;                                                                                 \
+            /* the wrapper sees "all remaining bytes"; any size >= the physical block is equivalent */                    \
+            { const uint64_t cs = phys < rem ? phys : rem; jobs[n].comp_size = cs > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cs; } \
+            jobs[n].out_off = (uint64_t)n * block_size;                                                                    \
+            jobs[n].out_len = block_size;                                                                                  \
+            n++;                                                                                                           \
+            if (verify && phys <= rem)                                                                                     \
+                global_hash = ((global_hash << 1) | (global_hash >> 31)) ^ rd32(src + ip + BLK_HDR + csz);                 \
+            if (phys >= rem) { ip = src_size; done = 1; break; }                                                           \
+            ip += (size_t)phys;                                                                                            \
+        }                                                                                                                  \
+        W[k].n = n;                                                                                                        \
+        W[k].span0 = span0;                                                                                                \
+        W[k].span = ip - span0;                                                                                            \
+        W[k].last = done;                                                                                                  \
+    } while (0)
+    int cur = 0;
+    WALK_BATCH(0);
+    const int my_dev = zxc_hip_current_device();
+    while (W[cur].n && ret == 0) {
+        const uint32_t n = W[cur].n;
+        zxc_dev_job_t* jobs = W[cur].jobs;
+        const size_t span0 = W[cur].span0, span = W[cur].span;
+        int32_t* st = W[cur].st;
+        int rc = ZXC_OK;
         dev_bufs_t b;
-        int rc = run_jobs(src + span0, span, jobs, n, (size_t)n * block_size, block_size, verify, st, &b, &dr);
+        if (!W[cur].uploaded) { /* the first batch, or one whose arena was busy when it was walked: this thread holds nothing here */
+            rc = jobs_upload(src + span0, span, jobs, n, (size_t)n * block_size, &W[cur].b, &dr, cur, NULL, NULL);
+            b = W[cur].b;
+            W[cur].n = 0; /* (from here on `b` owns the arena) */
+            if (rc == ZXC_OK) rc = jobs_execute(&b, n, block_size, 0u, verify, st, &dr, NULL);
+        } else { /* uploaded AND decoded by the helper, statuses in st */
+            b = W[cur].b;
+            W[cur].n = 0;
+        }
         if (rc != ZXC_OK) { ret = rc; break; }
+        /* the next batch: walked here, uploaded AND decoded by the helper (its own arena and stream) while this batch's output is
+         * copied back: three stages overlap — a launch costs ~0.5 ms whatever its size, serial per batch that was 0.6 ms of every
+         * batch (profiles/r4c_host_api.log) */
+        const int nxt = cur ^ 1;
+        host_upload_t up;
+        memset(&up, 0, sizeof up);
+        pthread_t up_thread;
+        int up_live = 0;
+        W[nxt].n = 0;
+        W[nxt].uploaded = 0;
+        if (!done) {
+            WALK_BATCH(nxt);
+            /* the other arena, if nobody holds it (never WAIT for a second arena while holding one: two such callers would
+             * wait for each other); else the batch is uploaded in series when this one is done */
+            arena_t* na = (W[nxt].n && my_dev >= 0 && my_dev < HOST_MAX_DEVICES) ? &g_arena[my_dev][nxt] : NULL;
+            if (na && !up_stream && zxc_hip_stream_create(&up_stream) != ZXC_OK) up_stream = NULL;
+            if (na && up_stream && pthread_mutex_trylock(&na->mu) == 0) {
+                up = (host_upload_t){src + W[nxt].span0, W[nxt].span, W[nxt].jobs, W[nxt].n, (size_t)W[nxt].n * block_size, &W[nxt].b, &dr,
+                                     nxt, up_stream, na, my_dev, ZXC_OK, block_size, verify, W[nxt].st};
+                up_live = pthread_create(&up_thread, NULL, host_upload_main, &up) == 0;
+                if (!up_live) host_upload_main(&up); /* (no thread: upload it here, in series) */
+                W[nxt].uploaded = 1;
+            }
+        }
         /* sequential semantics: first failing block wins; sizes accumulate in order. A block that is not the
          * frame's last and decodes to another size than block_size makes the frame irregular (legal, never
          * produced by the reference encoder): blocks no longer sit back to back in the slot layout. */
         int regular = 1;
         size_t batch_total = 0;
-        uint32_t good = n;
         for (uint32_t i = 0; i < n; i++) {
-            if (st[i] < 0) { ret = st[i]; good = i; break; }
-            if ((size_t)st[i] > dst_capacity - total - batch_total) { ret = ZXC_ERROR_DST_TOO_SMALL; good = i; break; }
-            if ((uint32_t)st[i] != block_size && !(done && i + 1 == n)) regular = 0;
+            if (st[i] < 0) { ret = st[i]; break; }
+            if ((size_t)st[i] > dst_capacity - total - batch_total) { ret = ZXC_ERROR_DST_TOO_SMALL; break; }
+            if ((uint32_t)st[i] != block_size && !(W[cur].last && i + 1 == n)) regular = 0;
             if ((uint32_t)st[i] > block_size) regular = 0;
             batch_total += (size_t)st[i];
         }
+        if (ret == 0 && regular) {
+            const int crc = zxc_mi355x_memcpy_d2h(dst + total, b.d_out, batch_total);
+            if (crc != ZXC_OK) ret = crc;
+        }
+        if (up_live) pthread_join(up_thread, NULL);
+        if (W[nxt].uploaded && up.rc != ZXC_OK) { /* a failed upload: its arena is ours to release */
+            if (ret == 0) ret = up.rc;
+            W[nxt].b.held = up.arena;
+            dev_bufs_free(&W[nxt].b);
+            W[nxt].n = 0;
+            W[nxt].uploaded = 0;
+        }
         if (ret == 0 && !regular) {
             /* decoded sizes are a property of the blocks alone: re-run this batch with one cap-sized slot
-             * per block and gather */
+             * per block and gather. (The prefetched batch gives its arena back first — this thread is about to wait for one —
+             * and goes up again, in series, when its turn comes.) */
+            if (W[nxt].uploaded) { dev_bufs_free(&W[nxt].b); W[nxt].uploaded = 0; }
             dev_bufs_free(&b);
             for (uint32_t i = 0; i < n; i++) { jobs[i].out_off = (uint64_t)i * slot; jobs[i].out_len = slot; }
-            rc = run_jobs(src + span0, span, jobs, n, (size_t)n * slot, block_size, verify, st, &b, &dr);
-            if (rc != ZXC_OK) { ret = rc; break; }
+            rc = run_jobs_on(src + span0, span, jobs, n, (size_t)n * slot, block_size, 0u, verify, st, &b, &dr, cur, NULL);
+            if (rc != ZXC_OK) { ret = rc; memset(&b, 0, sizeof b); }
             size_t op = total;
             for (uint32_t i = 0; i < n && rc == ZXC_OK; i++) {
                 /* the second run must reproduce the first one's verdicts: a status is never trusted as a copy length */
@@ -654,17 +644,17 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
                 rc = zxc_mi355x_memcpy_d2h(dst + op, (const uint8_t*)b.d_out + (size_t)i * slot, (size_t)st[i]);
                 op += (size_t)st[i];
             }
-            if (rc != ZXC_OK) ret = rc;
-        } else if (ret == 0) {
-            const int crc = xfer_d2h(dst + total, b.d_out, batch_total, NULL);
-            if (crc != ZXC_OK) ret = crc;
+            if (rc != ZXC_OK && ret == 0) ret = rc;
         }
-        (void)good;
         dev_bufs_free(&b);
         total += batch_total;
+        cur = nxt;
     }
-    free(jobs);
-    free(st);
+#undef WALK_BATCH
+    for (int k = 0; k < 2; k++)
+        if (W[k].n && W[k].uploaded) dev_bufs_free(&W[k].b); /* (an uploaded batch that is not going to run: give its arena back) */
+    zxc_hip_stream_destroy(up_stream);
+    for (int k = 0; k < 2; k++) { free(W[k].jobs); free(W[k].st); }
     if (ret < 0) return ret;
     if (tail_err) return tail_err;
     if (saw_eof) { /* footer: stored size must equal what was produced (zxc_dispatch.c:936-943) */
@@ -779,7 +769,7 @@ int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const 
         void* d_work = dict_size ? zxc_mi355x_malloc((size_t)zxc_mi355x_encode_dict_work_size(src_size, (uint32_t)block_size, (uint32_t)dict_size)) : NULL;
         int64_t rc = ZXC_ERROR_MEMORY;
         if (sizes && offs && d_src && d_slots && d_sizes && d_offs && (!dict_size || (d_dict && d_work))) {
-            rc = xfer_h2d(d_src, src, src_size, NULL);
+            rc = zxc_mi355x_memcpy_h2d(d_src, src, src_size);
             if (rc == ZXC_OK && dict_size) rc = zxc_mi355x_memcpy_h2d(d_dict, dict, dict_size);
             if (rc == ZXC_OK)
                 rc = dict_size ? zxc_mi355x_encode_blocks_dict_device(d_src, src_size, (uint32_t)block_size, level, checksum_enabled,
@@ -803,7 +793,7 @@ int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const 
                 rc = zxc_mi355x_gather_blocks_device(d_slots, (uint32_t)block_size, (const uint32_t*)d_sizes,
                                                      (const uint64_t*)d_offs, d_out, nb, NULL);
             if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(NULL);
-            if (rc == ZXC_OK) rc = xfer_d2h(dst + op, d_out, (size_t)total, NULL);
+            if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(dst + op, d_out, (size_t)total);
             if (rc == ZXC_OK && checksum_enabled) /* fold the block trailers in stream order (zxc_dispatch.c:754-759) */
                 for (uint32_t i = 0; i < nb; i++)
                     global_hash = ((global_hash << 1) | (global_hash >> 31)) ^ rd32(dst + op + offs[i] + sizes[i] - 4);
