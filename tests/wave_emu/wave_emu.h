@@ -156,6 +156,7 @@ template <typename T> inline T ntload(const void* p) { T v; memcpy(&v, p, sizeof
 #define __ffsll(x) __builtin_ffsll((long long)(x))
 #define __ffs(x) __builtin_ffs((int)(x))
 #define __umul24(a, b) (((uint32_t)(a) & 0xFFFFFFu) * ((uint32_t)(b) & 0xFFFFFFu))
+#define __umulhi(a, b) ((uint32_t)(((uint64_t)(uint32_t)(a) * (uint64_t)(uint32_t)(b)) >> 32))
 #define __umul64hi(a, b) ((uint64_t)(((unsigned __int128)(a) * (unsigned __int128)(b)) >> 64))
 inline uint32_t atomicCAS(uint32_t* p, uint32_t c, uint32_t v) { return emu::atomic_cas(p, c, v); }
 inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { return emu::atomic_add(p, v); }

@@ -151,13 +151,14 @@ __device__ __forceinline__ uint32_t prefix16(uint64_t a_lo, uint64_t a_hi, const
 //   GHI: 4-byte words), offsets (GLO), extras
 // HB = log2(head entries), CWB = log2(chain ring entries) or 0 for "head only". depth / sufficient / lazy: the
 // reference's search_depth / sufficient_len / lazy probes (src/lib/zxc_internal.h:965-979), see the table below.
-template <uint32_t HB, uint32_t CWB, bool GHI, uint32_t NC, uint32_t U>
+template <uint32_t HSZ, uint32_t CWB, bool GHI, uint32_t NC, uint32_t U>
 __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src, uint64_t src_size, uint32_t block_size,
                                                  uint8_t* __restrict__ slots, uint32_t slot_stride,
                                                  uint32_t* __restrict__ sizes, uint32_t n_blocks, uint32_t with_checksum,
                                                  uint32_t depth, uint32_t sufficient, uint32_t lazy, uint32_t dict_size,
                                                  uint8_t* __restrict__ huf_scratch, uint32_t huf) {
-    constexpr uint32_t HSIZE = 1u << HB;
+    constexpr uint32_t HSIZE = HSZ;  // head entries: any even number (the hash's top bits are scaled onto it), so that the tables can be
+                                     // cut to the LDS that buys one more workgroup per CU (160 KiB / 7 = 22.8 KiB)
     constexpr uint32_t CW = CWB ? (1u << CWB) : 1u;
     constexpr uint32_t CWM = CW - 1u;
     constexpr bool DEEP = CWB >= 13u;  // the levels 5-7 entry: the only one that carries the PivCo section encoder
@@ -212,8 +213,9 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         enc_lds_fence();
     };
     auto hash_of = [&](uint64_t v) -> uint32_t {  // zxc_hash_func, src/lib/zxc_compress.c:45-53: 5-byte / 4-byte variants
-        if (GHI) return (((uint32_t)v ^ ((uint32_t)v >> 15)) * 0x2D35182Du) >> (32u - HB);
-        return (uint32_t)(((v & 0xFFFFFFFFFFull) * 0x2545F4914F6CDD1Dull) >> (64u - HB));
+        // (top bits of the reference's hash, scaled to the table: for a power of two exactly its `>> (bits - log2 size)`)
+        if (GHI) return __umulhi(((uint32_t)v ^ ((uint32_t)v >> 15)) * 0x2D35182Du, HSIZE);
+        return __umulhi((uint32_t)(((v & 0xFFFFFFFFFFull) * 0x2545F4914F6CDD1Dull) >> 32), HSIZE);
     };
     // dictionary positions seed the tables (no search, no parse)
     for (uint32_t c0s = 0; c0s < D; c0s += 64u) {
@@ -289,6 +291,9 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         uint32_t triedA[U], dA[U];
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) { lenA[u] = 0; distA[u] = 0; triedA[u] = 0; dA[u] = d0A[u]; }
+#ifdef EXP_ENC_NOWALK  // (experiment, wrong output: no candidate is fetched or compared — lookup, publish, parse and emission only)
+        for (uint32_t u = 0; u < U; u++) dA[u] = 0;
+#endif
         for (;;) {
             bool actA[U];
             uint64_t anyact = 0;
@@ -414,6 +419,9 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         for (uint32_t u = 0; u < U; u++) {
             const uint32_t cu = c0 + 64u * u;
             if (cu >= n || overflow) break;
+#ifdef EXP_ENC_NOPARSE  // (experiment, wrong output: the match finder alone — nothing is parsed or emitted)
+            pos = cu + 64u; continue;
+#endif
             const uint32_t i = iA[u], len = lenA[u], dist = distA[u], bk = bkA[u];
             const uint64_t v = vA[u];
             const bool can = canA[u];
@@ -750,14 +758,17 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         encode_one_block<hb, cwb, ghi, nc, ENC_U>(src, src_size, block_size, slots, slot_stride, sizes, n_blocks, with_checksum,  \
                                        depth, sufficient, lazy, dict_size, huf_scratch, huf);                          \
     }
-ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l1, 12u, 0u, true, 5, 3u)    // level 1 (A/B: one candidate per round instead of three: -3 %)
-ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l2, 12u, 11u, true, 3, 3u)   // level 2
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l1, 4096u, 0u, true, 5, 3u)    // level 1 (A/B: one candidate per round instead of three: -3 %)
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l2, 4096u, 11u, true, 3, 3u)   // level 2
 #ifndef ENC_L34_HB  // (A/B: tools/build_enc_variant.sh)
 #define ENC_L34_HB 13u
 #define ENC_L34_CWB 12u
 #define ENC_L34_WAVES 2
 #endif
-ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l34, ENC_L34_HB, ENC_L34_CWB, false, ENC_L34_WAVES, 3u) // levels 3-4
+#ifndef ENC_L34_HSIZE
+#define ENC_L34_HSIZE (1u << ENC_L34_HB)
+#endif
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l34, ENC_L34_HSIZE, ENC_L34_CWB, false, ENC_L34_WAVES, 3u) // levels 3-4
 #ifndef ENC_L57_HB  // (A/B: tools/build_enc_variant.sh)
 #define ENC_L57_HB 13u   // (A/B at level 5 on text, head / ring: 2^14 / 2^14 3.70 GB/s ratio 2.301; 2^13 / 2^14 4.76, 2.287;
 #define ENC_L57_CWB 14u  //  2^14 / 2^13 4.99, 2.275; 2^13 / 2^13 6.30, 2.249: the head table is the cheaper one to halve)
@@ -765,7 +776,7 @@ ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l34, ENC_L34_HB, ENC_L34_CWB, false, E
 #ifndef ENC_L57_NC
 #define ENC_L57_NC 6u   // candidates per round of the deep levels (18 / 33 / 66 per position: half the round trips of 3)
 #endif
-ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l57, ENC_L57_HB, ENC_L57_CWB, false, 1, ENC_L57_NC) // levels 5-7
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l57, (1u << ENC_L57_HB), ENC_L57_CWB, false, 1, ENC_L57_NC) // levels 5-7
 
 // [dict | block b] images for the dictionary path: work + b * (block_size + dict_size)
 extern "C" __global__ void __launch_bounds__(64)
