@@ -233,6 +233,37 @@ def test_overflow_margin_frames_on_emulator(emu, oracle):
     assert codes == {"ok", -10}
 
 
+def test_checksum_verification_flags_exactly_the_damaged_blocks(emu, oracle, manifest):
+    """Per-block checksum verification in the decode kernels: a flipped payload bit or a flipped stored checksum gives BAD_CHECKSUM
+    (-7) for that block alone, whatever kernel decodes it, exactly like the oracle."""
+    import emu_py
+    names = [n for n, m in manifest["synth"].items() if m["checksum"] and m["size"] <= 400_000]
+    assert names
+    rng = random.Random(3)
+    seen_bad = 0
+    for name in names[:3]:
+        comp = read(f"synth/{name}.zxc")
+        jobs, bs, ck, total = emu_py.frame_jobs(comp)
+        assert ck
+        for rounds in range(3):
+            m = bytearray(comp)
+            hit = sorted(rng.sample(range(len(jobs)), min(len(jobs), 1 + rounds)))
+            for k in hit:
+                j = jobs[k]
+                size = int(j["comp_size"])
+                at = int(j["comp_off"]) + (size - 1 - rng.randrange(4) if rounds == 2 else 8 + rng.randrange(size - 12))  # the trailer itself / the payload
+                m[at] ^= 1 << rng.randrange(8)
+            m = bytes(m)
+            st, out = emu.decode_jobs(m, jobs, total, bs, verify_trailer=True)
+            for i, j in enumerate(jobs):
+                blk = m[int(j["comp_off"]):int(j["comp_off"]) + int(j["comp_size"])]
+                rc, want = oracle.decode_block(blk, bs, checksum=True)
+                assert st[i] == rc, (name, i, st[i], rc)
+                assert (rc == -7) == (i in hit), (name, i, rc)
+                seen_bad += rc == -7
+    assert seen_bad >= 6
+
+
 def test_rle_blocks_run_in_the_lean_kernel_and_fail_like_the_oracle(emu, oracle):
     """Round 4: blocks with RLE-coded literals and raw tokens are expanded and decoded by the lean kernel (slot of the scratch pool)
     instead of the one-wave full kernel. The golden RLE archive leaves the full kernel's list empty; 400 mutations of it (header
