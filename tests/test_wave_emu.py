@@ -128,6 +128,29 @@ def test_encoder_edge_cases_on_emulator(emu, ref, oracle):
     _enc_roundtrip(emu, ref, oracle, b"ABCDE" * 3000, 2, 4096)
 
 
+def test_optimal_parse_level6_on_emulator(emu, ref, oracle, synth_inputs):
+    """Level 6 runs the price-based optimal parse (zxc_optparse.inc; reference zxc_lz77_optimal_parse_glo, src/lib/zxc_compress.c:795-1042):
+    DP over the recorded longest matches, walk back through LDS windows, sequences emitted from the marked match ends. Every archive
+    decodes with the UNMODIFIED reference; edge sizes, the long-match skip (zeros, short periods), blocks of one literal run, small
+    block sizes and a dictionary; not larger than level 5's parse of the same data + 1 % (it adds the PivCo literal section); and
+    the literal price is the same on the emulator and on the device (integer log2)."""
+    rng = random.Random(11)
+    for n in (0, 1, 7, 8, 9, 63, 64, 65, 1023, 1024, 4097, 65535, 65536, 65537):
+        data = bytes(rng.getrandbits(8) & (0x07 if n % 2 else 0xFF) for _ in range(n))
+        _enc_roundtrip(emu, ref, oracle, data, 6)
+    _enc_roundtrip(emu, ref, oracle, bytes(140000), 6)                                    # zeros: one match per block, everything inside it skipped
+    _enc_roundtrip(emu, ref, oracle, b"abcdefghij" * 9000, 6, 131072)                     # period 10 across a 128 KiB block
+    _enc_roundtrip(emu, ref, oracle, bytes(rng.getrandbits(8) for _ in range(70000)), 6)  # incompressible: literals only, RAW blocks
+    _enc_roundtrip(emu, ref, oracle, (b"x" * 300 + bytes(range(256))) * 40, 6, 4096, checksum=True)
+    text = synth_inputs["mixed_384k"][:131072]
+    c6 = _enc_roundtrip(emu, ref, oracle, text, 6)
+    c5 = _enc_roundtrip(emu, ref, oracle, text, 5)
+    assert len(c6) <= 1.01 * len(c5), (len(c6), len(c5))
+    assert len(c6) <= 1.04 * len(ref.compress(text, 6, 65536, True, False))
+    t = oracle.seek_table(c6)
+    assert all(c6[o] in (0, 1) for o in t["comp_offsets"][:t["n_blocks"]])
+
+
 def test_encoder_rle_literals_on_emulator(emu, ref, oracle):
     """Runs shorter than the LZ minimum match survive as literals; the literal section is then RLE-coded
     (enc_lit = 1) like the reference's golden case 11 (tests/format/golden_cases.h:152-165)."""
@@ -153,7 +176,7 @@ def test_encoder_dictionary_on_emulator(emu, ref, oracle):
     name = sorted(f for f in os.listdir(os.path.join(GOLDEN, "conformance", "valid")) if f.startswith("dict_http") and f.endswith(".zxc"))[0]
     dict_id = int.from_bytes(read(f"conformance/valid/{name}")[7:11], "little")
     data = read(f"conformance/valid/{name[:-4]}.expected")[:20000] * 2
-    for level, bs in ((3, 4096), (1, 4096), (5, 65536)):
+    for level, bs in ((3, 4096), (1, 4096), (5, 65536), (6, 4096)):  # (6: the optimal parse over [dict | block] positions)
         comp = emu.encode(data, level, bs, dict_=d, dict_id=dict_id)
         plain = emu.encode(data, level, bs)
         o = oracle_py.DecompressOpts()

@@ -163,6 +163,7 @@ inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { return emu::atomic_add(p, v
 inline uint32_t atomicMax(uint32_t* p, uint32_t v) { return emu::atomic_max(p, v); }
 inline uint32_t atomicOr(uint32_t* p, uint32_t v) { return emu::atomic_or(p, v); }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return emu::atomic_add(p, v); }
+inline unsigned long long atomicMin(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; if (v < o) *p = v; return o; }
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __HIP_MEMORY_SCOPE_WORKGROUP 0
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))

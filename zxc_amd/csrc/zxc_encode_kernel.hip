@@ -35,6 +35,7 @@
 #include <stdint.h>
 
 #include "zxc_dev.h"
+#include "zxc_encode_levels.h"
 #include "zxc_rapidhash.inc"
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
@@ -145,6 +146,7 @@ __device__ __forceinline__ uint32_t prefix16(uint64_t a_lo, uint64_t a_hi, const
 }
 
 #include "zxc_pivco_encode.inc"
+#include "zxc_optparse.inc"
 
 // Slot layout while encoding (stride = 2*block_size + 512 bytes per block):
 //   [0,8) block header | [8,20) GLO/GHI header | literals ... | ... staging from block_size + 64: tokens (GLO: 1 B,
@@ -163,7 +165,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     constexpr uint32_t CWM = CW - 1u;
     constexpr bool DEEP = CWB >= 13u;  // the levels 5-7 entry: the only one that carries the PivCo section encoder
     __shared__ __attribute__((aligned(16))) uint16_t ht[HSIZE];  // head: low 16 bits of the most recent position with this hash
-    __shared__ uint16_t chain[CW];     // chain[q & CWM]: distance from q to the previous position with q's hash (0: none)
+    __shared__ __attribute__((aligned(16))) uint16_t chain[CW];  // chain[q & CWM]: distance from q to the previous position with q's hash (0: none)
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) return;
@@ -191,6 +193,17 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     if (CWB) for (uint32_t i = lane; i < CW / 2u; i += 64u) ((uint32_t*)chain)[i] = 0u;
     enc_lds_fence();
 
+    // Level 6 (the level table's ZXC_ENC_PARSE_OPTIMAL): the match finder only RECORDS the longest match of every position (mp[], in the block's PivCo scratch, which is
+    // idle until the sections are coded); the price-based optimal parse (zxc_optparse.inc) then picks the sequences.
+#ifdef EXP_NO_OPTPARSE  // (A/B: level 6 with the lazy parse of round 3)
+    const bool OPT = false;
+#elif defined(EXP_OPTPARSE_L7)  // (A/B: level 7 with the optimal parse too)
+    const bool OPT = DEEP && !GHI && huf != 0u;
+#else
+    const bool OPT = DEEP && !GHI && huf != 0u && lazy == ZXC_ENC_PARSE_OPTIMAL;
+#endif
+    uint32_t* const mp = OPT ? (uint32_t*)(huf_scratch + (uint64_t)b * 4u * ((uint64_t)block_size + 64u)) : nullptr;
+    uint32_t skip_until = 0;  // OPT: positions below it lie strictly inside a match of >= OPT_LONG_SKIP bytes and are not searched
     uint32_t seq_count = 0, lit_count = 0, ext_count = 0, max_off = 0;
     uint32_t pos = D;     // next position the parse will look at
     uint32_t anchor = D;  // end of the last emitted match
@@ -256,7 +269,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
             iA[u] = c0 + 64u * u + (uint32_t)lane;
-            canA[u] = iA[u] < limit && iA[u] >= D;
+            canA[u] = iA[u] < limit && iA[u] >= D && iA[u] >= skip_until;
             if (!fresh && canA[u]) v_next[u] = e_ld128(in + iA[u]);  // (a long match skipped ahead: the prefetch was for other chunks)
         }
         // request the following chunks' bytes now; they arrive while these are matched, parsed and emitted
@@ -419,6 +432,21 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         for (uint32_t u = 0; u < U; u++) {
             const uint32_t cu = c0 + 64u * u;
             if (cu >= n || overflow) break;
+            if (OPT) {  // levels 6-7: record, do not parse (reference: find_best_match inside the DP loop, zxc_compress.c:893-897)
+                uint32_t rl = lenA[u];
+                uint64_t lm = __ballot(rl >= OPT_LONG_SKIP);
+                while (lm) {  // a long match hides the positions inside it (ZXC_OPT_LONG_MATCH_SKIP, :956)
+                    const int j = __builtin_ctzll(lm);
+                    const uint32_t su = cu + (uint32_t)j + (uint32_t)__builtin_amdgcn_readlane((int)rl, j) - 1u;
+                    skip_until = su > skip_until ? su : skip_until;
+                    if (iA[u] > cu + (uint32_t)j && iA[u] < skip_until) rl = 0u;
+                    const uint32_t upto = skip_until - cu;  // lanes below it are settled
+                    lm &= upto >= 64u ? 0ull : ~((1ull << upto) - 1ull);
+                }
+                if (iA[u] >= D && iA[u] < n) mp[iA[u] - D] = rl >= 5u ? ((rl < 0xFFFFu ? rl : 0xFFFFu) | (distA[u] << 16)) : 0u;
+                pos = cu + 64u;
+                continue;
+            }
 #ifdef EXP_ENC_NOPARSE  // (experiment, wrong output: the match finder alone — nothing is parsed or emitted)
             pos = cu + 64u; continue;
 #endif
@@ -523,6 +551,20 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         if (pos > c0) c0 = pos & ~63u;
     }
     __builtin_amdgcn_s_waitcnt(0);
+    if (OPT && !overflow) {
+        // ---- levels 6-7: the optimal parse over the recorded matches. The match finder's tables are dead: the chain ring's LDS is
+        // the DP window, then the bitmap of match ends; the head table's LDS the histogram, the walk's window, the emitter's list.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // mp[] was written with ordinary stores
+        static_assert(!DEEP || (sizeof(uint16_t) * CW >= 8u * OPT_W && sizeof(uint16_t) * HSIZE >= 4u * OPT_W), "DP window / walk window must fit the tables");
+        const uint32_t litc = opt_lit_cost(in + D, nblk, (uint32_t*)ht, lane);
+        opt_dp(mp, nblk, litc, (unsigned long long*)chain, lane);
+        opt_backtrack(mp, nblk, (uint32_t*)ht, (uint32_t*)chain, lane);
+        OptOut oo;
+        if (!opt_emit(in + D, mp, nblk, (const uint32_t*)chain, (uint32_t*)ht, tok_st, off_st, ext_st, lit_out, max_seq, ext_cap, oo, lane)) overflow = true;
+        else { seq_count = oo.seq_count; lit_count = oo.lit_count; ext_count = oo.ext_count; max_off = oo.max_off; }
+        __builtin_amdgcn_s_waitcnt(0);
+    }
 
     // ---- RLE literal coding (GLO only): token < 0x80 copies token+1 raw bytes, >= 0x80 repeats the next byte
     // (token & 0x7F) + 4 times (src/lib/zxc_decompress.c:906-975). Chosen when rle_size + 3.125 % of the literal
