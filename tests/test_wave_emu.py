@@ -142,6 +142,7 @@ def test_optimal_parse_level6_on_emulator(emu, ref, oracle, synth_inputs):
     _enc_roundtrip(emu, ref, oracle, b"abcdefghij" * 9000, 6, 131072)                     # period 10 across a 128 KiB block
     _enc_roundtrip(emu, ref, oracle, bytes(rng.getrandbits(8) for _ in range(70000)), 6)  # incompressible: literals only, RAW blocks
     _enc_roundtrip(emu, ref, oracle, (b"x" * 300 + bytes(range(256))) * 40, 6, 4096, checksum=True)
+    _enc_roundtrip(emu, ref, oracle, (b"0123456789abcdef" * 37 + bytes(range(200))) * 400, 6, 262144)  # > OPT_MAX_BLOCK: the lazy parse
     text = synth_inputs["mixed_384k"][:131072]
     c6 = _enc_roundtrip(emu, ref, oracle, text, 6)
     c5 = _enc_roundtrip(emu, ref, oracle, text, 5)

@@ -198,9 +198,9 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
 #ifdef EXP_NO_OPTPARSE  // (A/B: level 6 with the lazy parse of round 3)
     const bool OPT = false;
 #elif defined(EXP_OPTPARSE_L7)  // (A/B: level 7 with the optimal parse too)
-    const bool OPT = DEEP && !GHI && huf != 0u;
+    const bool OPT = DEEP && !GHI && huf != 0u && block_size <= OPT_MAX_BLOCK;
 #else
-    const bool OPT = DEEP && !GHI && huf != 0u && lazy == ZXC_ENC_PARSE_OPTIMAL;
+    const bool OPT = DEEP && !GHI && huf != 0u && lazy == ZXC_ENC_PARSE_OPTIMAL && block_size <= OPT_MAX_BLOCK;
 #endif
     uint32_t* const mp = OPT ? (uint32_t*)(huf_scratch + (uint64_t)b * 4u * ((uint64_t)block_size + 64u)) : nullptr;
     uint32_t skip_until = 0;  // OPT: positions below it lie strictly inside a match of >= OPT_LONG_SKIP bytes and are not searched
