@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Condense the rocprofv3 CSV outputs of tools/profile.sh (gpurun_out/<tag>_{kt,fetch,write,sq,tcp}) into
-profiles/<tag>_summary.json + <tag>_kernel_stats.csv, and enter the launch's HBM traffic into profiles/r3_traffic.json
-(the table bench.py's roofline.traffic is read from).
+profiles/<tag>_summary.json + <tag>_kernel_stats.csv, and enter the launch's HBM traffic into profiles/r4_traffic.json
+(the table bench.py's roofline.traffic is read from) together with the content hash of the device sources that were profiled
+(bench.kernel_sources_hash(): bench.py reports the traffic only while that hash still matches its own tree).
 
 usage: profile_summary.py <tag> [decode|encode]
 
@@ -17,7 +18,7 @@ tag = sys.argv[1]
 what = sys.argv[2] if len(sys.argv) > 2 else "decode"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out"); P = os.path.join(ROOT, "profiles"); os.makedirs(P, exist_ok=True)
-DEC = ("zxc_decode_blocks_lean_kernel", "zxc_decode_blocks_kernel", "zxc_decode_blocks_lean_pre_kernel",
+DEC = ("zxc_decode_blocks_lean_kernel", "zxc_decode_blocks_kernel", "zxc_decode_blocks_lean_pre_kernel", "zxc_rle_expand_kernel",
        "zxc_pivco_sections_small_kernel", "zxc_pivco_sections_medium_kernel", "zxc_pivco_sections_large_kernel")
 GATHER_FACTOR, GATHER_BRACKET = 1.107, (1.0, 1.2)
 
@@ -118,7 +119,7 @@ if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
         algo = bench["roofline"]["algorithmic_bytes_per_launch"]
         out["hbm_traffic_bytes_per_launch"]["over_algorithmic"] = round((read + raw_w) / algo, 3)
         # the table bench.py reads
-        tp = os.path.join(P, "r3_traffic.json")
+        tp = os.path.join(P, "r4_traffic.json")
         tab = json.load(open(tp)) if os.path.exists(tp) else {}
         cfg = bench["config"]
         if what == "decode":
@@ -127,12 +128,15 @@ if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
         else:
             lvl = int(bench["metric"].split("level ")[1].split(",")[0])
             key, wl = f"encode_l{lvl}", {"enc_mib": int(cfg["workload"].split(": ")[1].split(" MiB")[0])}
+        sys.path.insert(0, ROOT)
+        import bench as _bench
         tab[key] = {"workload": wl, "bytes_per_launch": int(read + raw_w), "read": int(read), "write": int(raw_w),
+                    "kernels": _bench.kernel_sources_hash(),
                     "source": f"profiles/{tag}_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"}
         json.dump(tab, open(tp, "w"), indent=1)
 if "TCP_TCC_READ_REQ_sum" in pm:
     out["l1_to_l2_requests_per_launch"] = {"read": int(pm["TCP_TCC_READ_REQ_sum"]), "write": int(pm.get("TCP_TCC_WRITE_REQ_sum", 0)),
-                                           "note": "the CU's L1 hands ~0.1 request per clock to the L2 (profiles/r3_gather_sizes.log: 54 G lane-gathers/s chip-wide "
-                                                   "whatever level serves them): requests x 10 clk / (CUs x clock) bounds the launch from below"}
+                                           "note": "TCP_TCC_READ_REQ / WRITE_REQ summed over the launch's kernels (round 4: removing every far read — 1 760 of "
+                                                   "the ~2 435 read requests per level-3 block — is worth 14 % of the launch: profiles/r4e_ring_size_and_no_readback.log)"}
 json.dump(out, open(os.path.join(P, f"{tag}_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
