@@ -256,7 +256,7 @@ def encode_run(args, level, enc_mib, steps, warmup, comm, with_cpu_baseline=True
         return None
     kern_s = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)])) / 1e3
     algo = n + csize
-    entry = {1: "l1", 2: "l2", 3: "l34", 4: "l34"}.get(level, "l57")
+    entry = {1: "l1", 2: "l2", 3: "l3", 4: "l4"}.get(level, "l57")
     line = {
         "metric": f"device LZ77 hash-chain encode GB/s of source (level {level}, enwik-like text, {bs >> 10} KiB blocks, HBM-resident in/out)",
         "value": round(world * n * steps / wall / 1e9, 2), "unit": "GB/s", "n_gpus": world, "steps": steps,

@@ -14,7 +14,7 @@ timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_ept -o
 python - <<PY
 import csv, glob, collections, os
 G = "$R/gpurun_out"
-for kern in ("zxc_encode_blocks_kernel_l1", "zxc_encode_blocks_kernel_l34", "zxc_encode_blocks_kernel_l57"):
+for kern in ("zxc_encode_blocks_kernel_l1", "zxc_encode_blocks_kernel_l3", "zxc_encode_blocks_kernel_l57"):
     vals = {}
     for d in sorted(glob.glob(f"{G}/${tag}_ep[0-9]*")):
         f = os.path.join(d, "p_counter_collection.csv")

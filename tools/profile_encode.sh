@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/profile_encode.sh <tag> [level] : rocprofv3 passes of the encode bench (configs[2]): kernel trace + stats, then the
 # HBM traffic and instruction counters each in its own --pmc run -> gpurun_out/<tag>_{kt,fetch,write,sq}/ ;
-# condense with: python tools/profile_summary.py <tag> zxc_encode_blocks_kernel_l34
+# condense with: python tools/profile_summary.py <tag> zxc_encode_blocks_kernel_l3
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=$1; lv=${2:-3}

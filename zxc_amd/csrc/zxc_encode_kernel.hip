@@ -779,15 +779,15 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
 // sufficient_len 16/18/16/18/256/256/256, lazy probes 0/0/1/1(+ip+2)/1(+ip+2)/0/0; levels 1-2 emit GHI and use
 // the 4-byte hash, levels >= 3 GLO and the 5-byte hash. Here every position is inserted, so chains are denser
 // than the CPU's and the deep levels walk fewer links for the same reach; LDS per wave (= occupancy) grows with
-// the level: 8 / 12 / 24 / 24 / 48 / 48 / 48 KiB.
-//   level   head   chain ring   depth   sufficient   lazy   block type
-//     1     2^12      -           1        16          0      GHI
-//     2     2^12     2^11         3        18          0      GHI
-//     3     2^13     2^12         3        16          1      GLO
-//     4     2^13     2^12         6        18          2      GLO
-//     5     2^13     2^14        18       256          2      GLO
-//     6     2^13     2^14        33       256          2      GLO   (+ PivCo literals; lazy parse, not the reference's optimal parse)
-//     7     2^13     2^14        66       256          2      GLO
+// the level: 8 / 12 / 20 / 24 / 48 / 48 / 48 KiB.
+//   level   head   chain ring   depth   candidates per round   sufficient   parse     block type
+//     1     2^12      -           1          3                    16        greedy    GHI
+//     2     2^12     2^11         3          3                    18        greedy    GHI
+//     3     2^13     2^11         4          4                    16        lazy 2    GLO
+//     4     2^13     2^12         6          3                    18        lazy 2    GLO
+//     5     2^13     2^14        18          6                   256        lazy 2    GLO
+//     6     2^13     2^14        33          6                   256        optimal   GLO + PivCo literals (zxc_optparse.inc)
+//     7     2^13     2^14        66          6                   256        lazy 2    GLO + PivCo literals and tokens
 #ifndef ENC_U
 #define ENC_U 1u   // chunks of 64 positions in flight per loop iteration (A/B, profiles/r3p_encu.log: 1 / 2 / 3 / 4 all within 2 % at
                    // level 3 — a wave issues in order, only the memory round trips overlap — and 1 keeps the archives of round 2 byte for byte)
@@ -802,15 +802,21 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     }
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l1, 4096u, 0u, true, 5, 3u)    // level 1 (A/B: one candidate per round instead of three: -3 %)
 ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l2, 4096u, 11u, true, 3, 3u)   // level 2
-#ifndef ENC_L34_HB  // (A/B: tools/build_enc_variant.sh)
-#define ENC_L34_HB 13u
-#define ENC_L34_CWB 12u
-#define ENC_L34_WAVES 2
+// Level 3 (round 4): head 2^13 + ring 2^11 = 20 KiB -> EIGHT workgroups per CU = two waves on every SIMD instead of six (two SIMDs
+// with one wave and nothing to hide its round trips behind): +40 % at the same search effort, for 1.25 % of ratio (the ring's far
+// hops); four candidates in ONE round and two lazy probes buy 0.8 % back for 9 % of the time (profiles/r4f_encoder_ablations.log).
+#ifndef ENC_L3_HB  // (A/B: tools/build_enc_variant.sh)
+#define ENC_L3_HB 13u
+#define ENC_L3_CWB 11u
+#define ENC_L3_NC 4u
 #endif
-#ifndef ENC_L34_HSIZE
-#define ENC_L34_HSIZE (1u << ENC_L34_HB)
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l3, (1u << ENC_L3_HB), ENC_L3_CWB, false, 2, ENC_L3_NC) // level 3
+#ifndef ENC_L4_HB  // (A/B: tools/build_enc_variant.sh)
+#define ENC_L4_HB 13u
+#define ENC_L4_CWB 12u   // 24 KiB -> six per CU: level 4's size bound (1.05 x the reference, today 1.047 x) has nothing to spend on a smaller ring
+#define ENC_L4_NC 3u
 #endif
-ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l34, ENC_L34_HSIZE, ENC_L34_CWB, false, ENC_L34_WAVES, 3u) // levels 3-4
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l4, (1u << ENC_L4_HB), ENC_L4_CWB, false, 2, ENC_L4_NC) // level 4
 #ifndef ENC_L57_HB  // (A/B: tools/build_enc_variant.sh)
 #define ENC_L57_HB 13u   // (A/B at level 5 on text, head / ring: 2^14 / 2^14 3.70 GB/s ratio 2.301; 2^13 / 2^14 4.76, 2.287;
 #define ENC_L57_CWB 14u  //  2^14 / 2^13 4.99, 2.275; 2^13 / 2^13 6.30, 2.249: the head table is the cheaper one to halve)

@@ -50,7 +50,8 @@ extern "C" __global__ void zxc_decode_blocks_dict_kernel(const uint8_t* comp, co
                                     uint8_t* huf_scratch, uint32_t huf);
 ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l1)
 ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l2)
-ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l34)
+ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l3)
+ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l4)
 ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l57)
 extern "C" __global__ void zxc_prepend_dict_kernel(const uint8_t* src, uint64_t src_size, uint32_t block_size, const uint8_t* dict,
                                                    uint32_t dict_size, uint8_t* work, uint32_t n_blocks);
@@ -494,7 +495,10 @@ static int encode_launch(const void* d_src, uint64_t src_size, uint32_t block_si
         if (hipGetLastError() != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;  // (noticed here, not behind the encode launch)
         in = (const uint8_t*)d_work;
     }
-    const zxc_enc_level_t lp = zxc_enc_level(level);
+    zxc_enc_level_t lp = zxc_enc_level(level);
+#ifdef EXP_ENC_ENV  // (A/B builds only: search effort from the environment, "depth,sufficient,lazy")
+    if (const char* e = getenv("ZXC_EXP_ENC")) { unsigned a, b2, c; if (sscanf(e, "%u,%u,%u", &a, &b2, &c) == 3) { lp.depth = a; lp.sufficient = b2; lp.lazy = c; } }
+#endif
     uint8_t* huf_scratch = NULL;
     if (lp.huf) {
         // levels 6-7: level buffers + coded sections of the PivCo encoder, 4 x (block_size + 64) per block. Stream-ordered
@@ -504,7 +508,7 @@ static int encode_launch(const void* d_src, uint64_t src_size, uint32_t block_si
         if (hipMallocAsync((void**)&huf_scratch, need, (hipStream_t)stream) != hipSuccess || !huf_scratch) return ZXC_ERROR_MEMORY;
     }
     auto kern = lp.entry == 0 ? zxc_encode_blocks_kernel_l1 : lp.entry == 1 ? zxc_encode_blocks_kernel_l2
-              : lp.entry == 2 ? zxc_encode_blocks_kernel_l34 : zxc_encode_blocks_kernel_l57;
+              : lp.entry == 2 ? zxc_encode_blocks_kernel_l3 : lp.entry == 3 ? zxc_encode_blocks_kernel_l4 : zxc_encode_blocks_kernel_l57;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64), 0, (hipStream_t)stream, in, src_size, block_size,
                        (uint8_t*)d_slots, zxc_mi355x_encode_slot_stride(block_size), d_sizes, nb, with_checksum ? 1u : 0u,
                        lp.depth, lp.sufficient, lp.lazy, dict_size, huf_scratch, lp.huf);
