@@ -148,6 +148,19 @@ __device__ __forceinline__ uint32_t prefix16(uint64_t a_lo, uint64_t a_hi, const
 #include "zxc_pivco_encode.inc"
 #include "zxc_optparse.inc"
 
+// (experiment -DEXP_ENC_CLOCKS, tools/encclk.py: where a chunk's wall time goes. Every phase boundary waits for all outstanding
+//  loads, so a phase owns the memory round trips it asked for; sums over all blocks of a launch in shader clocks)
+#ifdef EXP_ENC_CLOCKS
+__device__ unsigned long long zxc_enc_clk[8];
+extern "C" __global__ void zxc_enc_clk_read_kernel(unsigned long long* out) {
+    if (threadIdx.x < 8u) { out[threadIdx.x] = zxc_enc_clk[threadIdx.x]; zxc_enc_clk[threadIdx.x] = 0ull; }
+}
+#define ENC_T(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t t_ = __builtin_readcyclecounter(); \
+                      clk_acc[k] += t_ - clk_last; clk_last = t_; } while (0)
+#else
+#define ENC_T(k) do { } while (0)
+#endif
+
 // Slot layout while encoding (stride = 2*block_size + 512 bytes per block):
 //   [0,8) block header | [8,20) GLO/GHI header | literals ... | ... staging from block_size + 64: tokens (GLO: 1 B,
 //   GHI: 4-byte words), offsets (GLO), extras
@@ -209,6 +222,10 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     uint32_t anchor = D;  // end of the last emitted match
     const uint32_t limit = n > ENC_MARGIN + 8u ? n - ENC_MARGIN - 8u : 0u;  // last position that may start a match (exclusive)
     bool overflow = false;
+#ifdef EXP_ENC_CLOCKS
+    uint64_t clk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t clk_last = __builtin_readcyclecounter();
+#endif
 
     // publish positions of a chunk: chain link = distance to the old head, head = own position
     auto publish = [&](uint32_t i, bool ins, uint32_t h, uint32_t d0) {
@@ -260,6 +277,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
 #pragma unroll
     for (uint32_t u = 0; u < U; u++) { const v4u z = {0, 0, 0, 0}; v_next[u] = z; }
     uint32_t c_next = 0xFFFFFFFFu;
+    ENC_T(0);  // set-up: tables cleared, dictionary seeded
     while (c0 < n && !overflow) {
         uint32_t iA[U], hA[U], d0A[U], lenA[U], distA[U], bkA[U];
         bool canA[U];
@@ -300,6 +318,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             enc_lds_fence();
             publish(iA[u], canA[u], h, d0);
         }
+        ENC_T(1);  // own bytes (prefetched) + hash + head lookup + publish
         // ---- 2. chain walks of the U chunks, NC candidates per chunk and round (zxc_lz77_find_best_match :262-440)
         uint32_t triedA[U], dA[U];
 #pragma unroll
@@ -351,6 +370,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
                     dkA[u][k + 1] = next(u, dkA[u][k], triedA[u] + k + 1u < depth);
                 }
             }
+            ENC_T(2);  // chain links + the round's candidate requests, until their bytes are here
 #pragma unroll
             for (uint32_t u = 0; u < U; u++) {
                 const uint32_t i = iA[u];
@@ -379,6 +399,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
                     lk[k] = mk[k] == 32u;
                     anylive |= lk[k];
                 }
+                ENC_T(3);  // first compares + the second 16 bytes
                 // candidates still equal after 32 bytes are extended TOGETHER, 16 bytes per step: one request for my own
                 // bytes and one per live candidate, all in flight at once, so a step costs one memory round trip however
                 // many candidates are still running (the reference extends them one after the other, 8 bytes at a time)
@@ -409,6 +430,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
                     }
                     // (the tail path above clamps at n; a 16 / 32-byte prefix that straddles the block end is clamped below)
                 }
+                ENC_T(4);  // extension of candidates equal over 32 bytes
 #pragma unroll
                 for (uint32_t k = 0; k < NC; k++)
                     if (mk[k] > lenA[u]) { lenA[u] = mk[k]; distA[u] = dkA[u][k]; }   // (first = nearest wins ties: smaller offsets, cheaper tokens)
@@ -459,35 +481,38 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             const uint32_t i = iA[u], len = lenA[u], dist = distA[u], bk = bkA[u];
             const uint64_t v = vA[u];
             const bool can = canA[u];
-            // ---- 4. scalar parse of the chunk: greedy + the level's lazy probes + backward extension
-            uint64_t sel = 0;
-            uint32_t ext_v = 0;  // per selected lane: bytes its match grew backwards
-            uint32_t p = pos > cu ? pos - cu : 0u;
-            uint32_t floor_p = p;  // chunk positions below this are consumed
+            ENC_T(5);  // (round bookkeeping, backward extension)
+            // ---- 4. parse of the chunk: greedy + the level's lazy probes + backward extension. What the parse does AT a position
+            // depends on that position and the two behind it only, so every lane settles its own position first — take my match and
+            // go to its end, or step 1 / 2 bytes to a clearly longer one (lazy_len_threshold 128) — and the scalar loop only hops
+            // from one visited match position to the next (one v_readlane per hop; round 3 evaluated the probes in the loop, four
+            // v_readlane -> s_cmp round trips per sequence: 27 % of the level-3 launch, profiles/r4f_encoder_ablations.log).
             const uint64_t has = __ballot(len >= 5u);  // positions where a match starts
+            uint32_t hop = (uint32_t)lane + len;       // where the parse stands after my position, relative to the chunk
+            bool take = len >= 5u;
+            if (lazy >= 1u) {
+                const uint32_t s1 = __shfl(len, (lane + 1) & 63), s2 = __shfl(len, (lane + 2) & 63);  // (every lane takes part: no select around them)
+                const uint32_t L1 = lane + 1 < 64 ? s1 : 0u;
+                const uint32_t L2 = (lazy >= 2u && lane + 2 < 64) ? s2 : 0u;
+                if (take && len < 128u) {
+                    if (L1 > len + 1u) { take = false; hop = (uint32_t)lane + 1u; }        // a clearly longer match starts one byte later
+                    else if (L2 > len + 2u) { take = false; hop = (uint32_t)lane + 2u; }
+                }
+            }
+            const uint64_t takes = __ballot(take);
+            uint64_t sel = 0;
+            uint32_t p = pos > cu ? pos - cu : 0u;
             const uint32_t pend = (n - cu < 64u) ? n - cu : 64u;
             while (p < pend) {
                 const uint64_t ahead = has >> p;
                 if (ahead == 0ull) { p = pend; break; }  // nothing left in this chunk: all literals
                 p += (uint32_t)__builtin_ctzll(ahead);
                 if (p >= pend) { p = pend; break; }
-                const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)p);
-                if (lazy >= 1u && L < 128u) {  // (lazy_len_threshold 128)
-                    const uint32_t L1 = (p + 1u < 64u) ? (uint32_t)__builtin_amdgcn_readlane((int)len, (int)(p + 1u)) : 0u;
-                    if (L1 > L + 1u) { p++; continue; }  // a clearly longer match starts one byte later
-                    if (lazy >= 2u) {
-                        const uint32_t L2 = (p + 2u < 64u) ? (uint32_t)__builtin_amdgcn_readlane((int)len, (int)(p + 2u)) : 0u;
-                        if (L2 > L + 2u) { p += 2u; continue; }
-                    }
-                }
-                uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)bk, (int)p);
-                e = e < p - floor_p ? e : p - floor_p;
-                ext_v = ((uint32_t)lane == p) ? e : ext_v;  // (v_cmp + v_cndmask with scalar sources)
-                sel |= 1ull << p;
-                p += L;
-                floor_p = p;
+                sel |= ((takes >> p) & 1ull) << p;
+                p = (uint32_t)__builtin_amdgcn_readlane((int)hop, (int)p);
             }
             const uint32_t next_pos = cu + p;
+            ENC_T(6);  // scalar parse
 
             // ---- 5. emit sequences and literals
             const bool issel = (sel >> lane) & 1ull;
@@ -495,6 +520,9 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             const int prevlane = below ? 63 - __builtin_clzll(below) : 0;
             const uint32_t prev_end = __shfl(i + len, prevlane);       // end of the previous selected match (or the carried anchor)
             const uint32_t lit_start = below ? prev_end : anchor;
+            // bytes my match grows backwards: not into the previous match (or in front of where the parse stood at the chunk's start)
+            const uint32_t floor_abs = below ? prev_end : (pos > cu ? pos : cu);
+            const uint32_t ext_v = (issel && bk) ? (bk < i - floor_abs ? bk : i - floor_abs) : 0u;
             const uint32_t mstart = i - ext_v;                          // where my match starts after growing backwards
             const uint32_t ll = issel ? mstart - lit_start : 0u;
             const uint32_t mlm = issel ? len + ext_v - 5u : 0u;
@@ -551,12 +579,16 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
                 anchor = __shfl(i + len, last);
             }
             pos = next_pos;
+            ENC_T(7);  // emission
         }
         // a match reaching past these chunks: skip the chunks it covers entirely
         c0 += 64u * U;
         if (pos > c0) c0 = pos & ~63u;
     }
     __builtin_amdgcn_s_waitcnt(0);
+#ifdef EXP_ENC_CLOCKS
+    if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&zxc_enc_clk[k], (unsigned long long)clk_acc[k]);
+#endif
     if (OPT && !overflow) {
         // ---- levels 6-7: the optimal parse over the recorded matches. The match finder's tables are dead: the chain ring's LDS is
         // the DP window, then the bitmap of match ends; the head table's LDS the histogram, the walk's window, the emitter's list.

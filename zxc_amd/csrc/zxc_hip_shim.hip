@@ -48,6 +48,17 @@ extern "C" __global__ void zxc_decode_blocks_dict_kernel(const uint8_t* comp, co
                                     uint32_t slot_stride, uint32_t* sizes, uint32_t n_blocks, uint32_t with_checksum,  \
                                     uint32_t depth, uint32_t sufficient, uint32_t lazy, uint32_t dict_size,        \
                                     uint8_t* huf_scratch, uint32_t huf);
+#ifdef EXP_ENC_CLOCKS  // (experiment build only, tools/encclk.py)
+extern "C" __global__ void zxc_enc_clk_read_kernel(unsigned long long* out);
+extern "C" __attribute__((visibility("default"))) int zxc_mi355x_exp_enc_clocks(unsigned long long* out8) {
+    unsigned long long* d = NULL;
+    if (hipMalloc((void**)&d, 64) != hipSuccess) return -1;
+    hipLaunchKernelGGL(zxc_enc_clk_read_kernel, dim3(1), dim3(64), 0, 0, d);
+    const hipError_t e = hipMemcpy(out8, d, 64, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return e == hipSuccess ? 0 : -1;
+}
+#endif
 ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l1)
 ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l2)
 ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l3)
