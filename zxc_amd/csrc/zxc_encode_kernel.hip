@@ -503,13 +503,17 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             uint64_t sel = 0;
             uint32_t p = pos > cu ? pos - cu : 0u;
             const uint32_t pend = (n - cu < 64u) ? n - cu : 64u;
-            while (p < pend) {
-                const uint64_t ahead = has >> p;
-                if (ahead == 0ull) { p = pend; break; }  // nothing left in this chunk: all literals
-                p += (uint32_t)__builtin_ctzll(ahead);
-                if (p >= pend) { p = pend; break; }
-                sel |= ((takes >> p) & 1ull) << p;
-                p = (uint32_t)__builtin_amdgcn_readlane((int)hop, (int)p);
+            {
+                // ... and where the next match at or behind a position starts (the chunk's end if none): a hop lands there at once
+                const uint64_t mine = has >> lane;
+                const uint32_t nm = mine ? (uint32_t)lane + (uint32_t)__builtin_ctzll(mine) : pend;
+                const uint32_t landed = __shfl(nm, (int)(hop & 63u));
+                hop = hop < 64u ? landed : hop;
+                if (p < pend) { const uint64_t ahead = has >> p; p = ahead ? p + (uint32_t)__builtin_ctzll(ahead) : pend; }
+                while (p < pend) {
+                    sel |= ((takes >> p) & 1ull) << p;
+                    p = (uint32_t)__builtin_amdgcn_readlane((int)hop, (int)p);
+                }
             }
             const uint32_t next_pos = cu + p;
             ENC_T(6);  // scalar parse
