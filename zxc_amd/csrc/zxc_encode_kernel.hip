@@ -288,7 +288,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
         for (uint32_t u = 0; u < U; u++) {
             iA[u] = c0 + 64u * u + (uint32_t)lane;
             canA[u] = iA[u] < limit && iA[u] >= D && iA[u] >= skip_until;
-            if (!fresh && canA[u]) v_next[u] = e_ld128(in + iA[u]);  // (a long match skipped ahead: the prefetch was for other chunks)
+            if (!fresh && iA[u] < n) v_next[u] = e_ld128(in + iA[u]);  // (a long match skipped ahead: the prefetch was for other chunks)
         }
         // request the following chunks' bytes now; they arrive while these are matched, parsed and emitted
         c_next = c0 + 64u * U;
@@ -298,7 +298,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             vA[u] = (uint64_t)v_next[u].x | ((uint64_t)v_next[u].y << 32);
             vhA[u] = (uint64_t)v_next[u].z | ((uint64_t)v_next[u].w << 32);
             const uint32_t i2 = c_next + 64u * u + (uint32_t)lane;
-            if (i2 < limit) v_next[u] = e_ld128(in + i2);
+            if (i2 < n) v_next[u] = e_ld128(in + i2);  // (every position of the block: its low byte is the literal the emission stores)
             // my own second 16 bytes: the same for every round of the walk (may reach up to 16 bytes past the block: lengths
             // are clamped to it below)
             own2A[u] = e_ld128((canA[u] ? in + iA[u] : in) + 16u);
@@ -480,7 +480,6 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
 #endif
             const uint32_t i = iA[u], len = lenA[u], dist = distA[u], bk = bkA[u];
             const uint64_t v = vA[u];
-            const bool can = canA[u];
             ENC_T(5);  // (round bookkeeping, backward extension)
             // ---- 4. parse of the chunk: greedy + the level's lazy probes + backward extension. What the parse does AT a position
             // depends on that position and the two behind it only, so every lane settles its own position first — take my match and
@@ -570,10 +569,10 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             // literal = in range, not inside a match, and already passed by the parse
             const bool islit = i < n && i >= cover_until && i < next_pos && !in_next;
             const uint64_t litmask = __ballot(islit);
-            // (the byte is already here: low byte of the 16 fetched for this position; only the block's last 16
-            // positions, which never start a match, were not fetched)
+            // (the byte is already here: low byte of the 16 fetched for this position. No load in the emission: a load whose result a
+            // store needs makes the wave wait for every store in front of it, i.e. for this chunk's own sequence stores)
     #ifndef EXP_ENC_NOSTORE
-            if (islit) lit_out[lit_count + __popcll(litmask & lt_mask)] = can ? (uint8_t)v : (uint8_t)e_ld8(in + i);
+            if (islit) lit_out[lit_count + __popcll(litmask & lt_mask)] = (uint8_t)v;
     #endif
             lit_count += __popcll(litmask);
             seq_count += nsel;
