@@ -53,6 +53,25 @@ def tile_bytes(tile, block_size, pool):
 CPU_BASELINE_TILES = 4  # the cpu_baseline sample: ONE reference-written archive of this many corpus tiles
 
 
+def _ref_compress_cached(ref, key, data, level, block_size, seekable, checksum):
+    """ref.compress, kept on disk when ZXC_BENCH_CACHE names a directory (tools/profile.sh: its five rocprofv3 passes run the same
+    command on the same box; the reference encoder is untimed input preparation, 100 s per pass at level 7). Off by default."""
+    d = os.environ.get("ZXC_BENCH_CACHE")
+    if not d:
+        return ref.compress(data, level, block_size, seekable, checksum)
+    os.makedirs(d, exist_ok=True)
+    import hashlib
+    path = os.path.join(d, f"{hashlib.sha1(key.encode()).hexdigest()[:16]}_n{len(data)}_l{level}_b{block_size}_s{int(seekable)}_c{int(checksum)}.zxc")
+    if os.path.exists(path):
+        return open(path, "rb").read()
+    comp = ref.compress(data, level, block_size, seekable, checksum)
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with open(tmp, "wb") as f:
+        f.write(comp)
+    os.replace(tmp, path)
+    return comp
+
+
 def build_rank_corpus(first, last, level, block_size, pool, dev, checksum=False, baseline_tiles=0):
     """Blocks [first, last) of the global corpus, encoded by the unmodified reference (the metric is defined on
     archives written by the reference encoder: "silesia.tar at -3"; untimed input preparation). Only the tiles
@@ -82,10 +101,10 @@ def build_rank_corpus(first, last, level, block_size, pool, dev, checksum=False,
             if len(base_data) < baseline_tiles:  # the CPU baseline's archive: the first tiles as ONE seekable archive
                 base_data.append(data)
                 if len(base_data) == min(baseline_tiles, len(tiles)):
-                    base_fut = tp.submit(ref.compress, b"".join(base_data), level, block_size, True, False)
+                    base_fut = tp.submit(_ref_compress_cached, ref, f"base{tiles[0]}x{len(base_data)}_{src}", b"".join(base_data), level, block_size, True, False)
             lo, hi = max(first, t * tb) - t * tb, min(last, (t + 1) * tb) - t * tb
             wants.append(torch.frombuffer(bytearray(data[lo * block_size: hi * block_size]), dtype=torch.uint8).to(dev))
-            futs.append((lo, hi, tp.submit(ref.compress, data, level, block_size, True, checksum)))
+            futs.append((lo, hi, tp.submit(_ref_compress_cached, ref, f"tile{t}_{src}", data, level, block_size, True, checksum)))
             del data
         for lo, hi, f in futs:
             comp = f.result()

@@ -27,10 +27,10 @@ for cname, data in classes.items():
                 n += 1
                 if not ok:
                     bad += 1; print("FAIL decode", cname, level, bs, ck, out[0] if isinstance(out, tuple) else None, flush=True)
-        if level in (1, 3, 5):
-            comp = zxc_amd.compress(data, level, 65536, True, level == 5)
+        for bs in (4096, 65536, 524288, 2097152):  # device encoder -> reference decoder, every level and block size
+            comp = zxc_amd.compress(data, level, bs, True, level == 5)
             rc, out = ref.decompress(comp, len(data), checksum=(level == 5))
             n += 1
             if rc != len(data) or out != data:
-                bad += 1; print("FAIL encode", cname, level, rc, flush=True)
+                bad += 1; print("FAIL encode", cname, level, bs, rc, flush=True)
 print(f"{n} cases, {bad} failures, {time.time() - t0:.0f} s")
