@@ -12,24 +12,25 @@
 //      most recent position with that hash; chain[] in LDS (a ring over the last 2^CWB positions) links every
 //      position to the previous one with the same hash. EVERY position is inserted (the CPU inserts only the
 //      positions its parse visits), so a chain here is denser than the reference's and needs fewer steps;
-//   2. each lane walks its own chain for up to `depth` candidates, three per round: the links are LDS reads,
+//   2. each lane walks its own chain for up to `depth` candidates, three to six per round: the links are LDS reads,
 //      32 bytes of every candidate are requested as soon as its distance is known (one memory round trip per
 //      round), compared with 64-bit XOR + ctz, the longest kept; candidates still equal after 32 bytes are
 //      extended together, 16 bytes per step (A/B: 32 bytes per step with every load unconditional is 3 % slower
 //      at level 3, the same at levels 5-7); the walk stops at `sufficient` bytes like the reference's;
 //   3. the chunk's positions are published: chain link = distance to the old head, head = own position; lanes
 //      that share a bucket resolve it deterministically (highest position wins, re-checked until stable);
-//   4. the scalar unit walks the chunk's match lengths with v_readlane: greedy parse with the level's lazy
-//      probes (ip+1, ip+2), each accepted match extended backwards over equal preceding bytes down to the
-//      previous match's end (the reference's backtrack); a match that reaches past the chunk makes the wave
-//      skip whole chunks;
+//   4. greedy parse with the level's lazy probes (ip+1, ip+2): every lane settles its own position (take my match,
+//      or step to a clearly longer one), the scalar unit only hops from one visited match position to the next
+//      (one v_readlane per hop); each accepted match is extended backwards over equal preceding bytes down to
+//      the previous match's end (the reference's backtrack); a match that reaches past the chunk makes the wave
+//      skip whole chunks. Level 6 records the matches instead and runs the optimal parse (zxc_optparse.inc);
 //   5. selected lanes emit token / offset / varints (GLO) or 32-bit sequence words (GHI, levels 1-2) at
 //      wave-prefix-sum positions; bytes not covered by a match stream into the literal section.
 // Finally the literal section is RLE-coded when that is smaller by the reference's margin
 // (zxc_compress.c:1270-1534, :1671-1722), the sections are slid together into the reference's layout, or
 // the block is stored RAW when that is not smaller. Levels differ in effort (table sizes, chain depth,
 // sufficient length, lazy probes: table at the bottom); levels 6-7 code the literal section (7: and the token
-// section) with PivCo (zxc_pivco_encode.inc). Not done here: the level-6/7 optimal parse. Output is a valid v8
+// section) with PivCo (zxc_pivco_encode.inc). Output is a valid v8
 // block, round-trip-checked by tests/ against the unmodified reference decoder; archive bytes are deterministic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -263,7 +264,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
 
     // The main loop takes ENC_U chunks of 64 positions per iteration (round 3 experiment, kept as a template parameter). A
     // chunk's work is a chain of dependent steps — head lookup, publish, chain links, candidate bytes from memory, parse,
-    // emission — and a workgroup owns 24-48 KiB of tables, so only 3-6 waves share a CU and every unit is under half busy
+    // emission — and a workgroup owns 20-48 KiB of tables, so only 3-8 waves share a CU and every unit is under half busy
     // (profiles/r3enc_kprof.txt: ~850 instructions, 500 of them scalar, per chunk at ~12 clocks each). With U chunks in flight
     // the candidate loads of all of them are one memory round trip — measured worth nothing (profiles/r3p_encu.log): the
     // wave issues in order and its own dependent ALU / LDS / scalar chains are the time, not the memory round trips.
