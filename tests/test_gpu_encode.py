@@ -160,3 +160,22 @@ def test_dictionary_compression(gpu, oracle, ref):
         assert V.decompress_block(dst.raw[:rc], len(blk_data) + 2112, dict_=d) == (len(blk_data), blk_data)
     P.close()
     RB.close()
+
+
+def test_batched_compress_writes_the_same_archive(gpu, oracle, ref, monkeypatch):
+    """zxc_compress pipelines frames of more than one batch (helper thread: upload + encode of batch i + 1 beside offsets +
+    gather + download of batch i). The archive must be byte for byte the one-shot one — checksummed, seekable, a ragged last
+    block — and an output buffer that is too small must still answer DST_TOO_SMALL."""
+    from zxc_amd import corpus
+    data = corpus.synth_silesia(5 * (1 << 20) + 12345, seed=21)
+    for level, ck in ((3, True), (1, False), (6, False)):
+        monkeypatch.setenv("ZXC_MI355X_FRAME_BATCH_MIB", "1024")
+        one = gpu.compress(data, level, 65536, True, ck)
+        monkeypatch.setenv("ZXC_MI355X_FRAME_BATCH_MIB", "1")   # 16 blocks per batch -> 6 batches
+        many = _check(gpu, oracle, ref, data, level, 65536, True, ck)
+        assert many == one, (level, len(many), len(one))
+    import ctypes as C
+    from zxc_amd import api
+    dst = C.create_string_buffer(len(one) - 1)
+    o = api._CompressOpts(level=6, block_size=65536, seekable=1, checksum_enabled=0)
+    assert gpu.lib().zxc_compress(data, len(data), dst, len(dst), C.byref(o)) == -2  # ZXC_ERROR_DST_TOO_SMALL, from the last batch

@@ -16,7 +16,9 @@
 #include <limits.h>
 #include <pthread.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
+#include <time.h>
 
 #include "../../include/zxc.h"
 
@@ -716,6 +718,136 @@ static void wr64(uint8_t* p, uint64_t v) {
     wr32(p + 4, (uint32_t)(v >> 32));
 }
 
+/* zxc_compress over batches of blocks (round 4): a helper thread uploads batch i + 1 and launches its encode on that slot's
+ * stream while this thread turns batch i's block sizes into offsets, compacts the slots (zxc_gather_blocks_kernel) and brings
+ * the bytes back — H2D, kernel and D2H of neighbouring batches overlap. One-shot this was 1 GiB in 56 ms = H2D + 29 ms of
+ * kernel + D2H in series; batched 44 ms, now bound by the encode launches themselves (2 048 blocks = one workgroup per slot of
+ * the chip, under the copies' traffic); a second upload thread and 96-384 MiB batches measured the same
+ * (profiles/r4c_host_api.log; ZXC_MI355X_DEBUG_TIMES=1 prints the phases). */
+typedef struct {
+    void *d_src, *d_slots, *d_sizes, *d_offs, *d_out, *stream;
+} comp_slot_t;
+typedef struct {
+    const uint8_t* src;
+    size_t bytes;
+    uint32_t block_size;
+    int level, checksum, device, rc;
+    comp_slot_t* s;
+} comp_up_t;
+static void* comp_up_main(void* arg) {
+    comp_up_t* u = (comp_up_t*)arg;
+    u->rc = zxc_mi355x_set_device(u->device);
+    if (u->rc == ZXC_OK) u->rc = zxc_hip_memcpy_h2d_async(u->s->d_src, u->src, u->bytes, u->s->stream);
+    if (u->rc == ZXC_OK)
+        u->rc = zxc_mi355x_encode_blocks_device(u->s->d_src, u->bytes, u->block_size, u->level, u->checksum, u->s->d_slots,
+                                                (uint32_t*)u->s->d_sizes, u->s->stream);
+    return NULL;
+}
+static void comp_slot_free(comp_slot_t* s) {
+    zxc_mi355x_free(s->d_src);
+    zxc_mi355x_free(s->d_slots);
+    zxc_mi355x_free(s->d_sizes);
+    zxc_mi355x_free(s->d_offs);
+    zxc_mi355x_free(s->d_out);
+    zxc_hip_stream_destroy(s->stream);
+    memset(s, 0, sizeof *s);
+}
+/* -> ZXC_OK and *op_io advanced over the nb encoded blocks, sizes[] and *hash_io filled; or a negative zxc_error_t */
+static int compress_batches(const uint8_t* src, size_t src_size, size_t block_size, int level, int checksum_enabled, size_t tail_need,
+                            uint8_t* dst, size_t dst_capacity, size_t* op_io, uint32_t* sizes, uint32_t nb, uint32_t batch_blocks,
+                            uint32_t* hash_io) {
+    const uint32_t stride = zxc_mi355x_encode_slot_stride((uint32_t)block_size);
+    const size_t batch_bytes = (size_t)batch_blocks * block_size;
+    const int device = zxc_hip_current_device();
+    const int dbg = getenv("ZXC_MI355X_DEBUG_TIMES") != NULL;
+    struct timespec t_[8];
+#define TS(k) do { if (dbg) clock_gettime(CLOCK_MONOTONIC, &t_[k]); } while (0)
+#define MS(a, b) ((t_[b].tv_sec - t_[a].tv_sec) * 1e3 + (t_[b].tv_nsec - t_[a].tv_nsec) / 1e6)
+    TS(0);
+    comp_slot_t S[2];
+    memset(S, 0, sizeof S);
+    uint64_t* offs = (uint64_t*)malloc((size_t)batch_blocks * sizeof(uint64_t));
+    int rc = offs ? ZXC_OK : ZXC_ERROR_MEMORY;
+    for (int k = 0; k < 2 && rc == ZXC_OK; k++) {
+        S[k].d_src = zxc_mi355x_malloc(batch_bytes + 64);
+        S[k].d_slots = zxc_mi355x_malloc((size_t)batch_blocks * stride);
+        S[k].d_sizes = zxc_mi355x_malloc((size_t)batch_blocks * 4);
+        S[k].d_offs = zxc_mi355x_malloc((size_t)batch_blocks * 8);
+        S[k].d_out = zxc_mi355x_malloc((size_t)batch_blocks * (block_size + 64) + 64); /* (a block is never larger than RAW: header + bytes + trailer) */
+        if (!S[k].d_src || !S[k].d_slots || !S[k].d_sizes || !S[k].d_offs || !S[k].d_out) rc = ZXC_ERROR_MEMORY;
+        if (rc == ZXC_OK) rc = zxc_hip_stream_create(&S[k].stream);
+    }
+    size_t op = *op_io;
+    uint32_t global_hash = *hash_io;
+    const uint32_t nbatches = (nb + batch_blocks - 1) / batch_blocks;
+    comp_up_t up;
+    memset(&up, 0, sizeof up);
+    TS(1);
+    if (dbg) fprintf(stderr, "[zxc_compress] device buffers + streams %.2f ms\n", MS(0, 1));
+    if (rc == ZXC_OK) { /* batch 0: uploaded and launched here */
+        up = (comp_up_t){src, src_size < batch_bytes ? src_size : batch_bytes, (uint32_t)block_size, level, checksum_enabled, device, ZXC_OK, &S[0]};
+        comp_up_main(&up);
+        rc = up.rc;
+    }
+    for (uint32_t bi = 0; bi < nbatches && rc == ZXC_OK; bi++) {
+        comp_slot_t* s = &S[bi & 1];
+        const uint32_t b0 = bi * batch_blocks, nbi = nb - b0 < batch_blocks ? nb - b0 : batch_blocks;
+        pthread_t th;
+        int live = 0, started = 0;
+        if (bi + 1 < nbatches) { /* the next batch, on the other slot (its last user, batch bi - 1, is done) */
+            const size_t o = (size_t)(bi + 1) * batch_bytes;
+            up = (comp_up_t){src + o, src_size - o < batch_bytes ? src_size - o : batch_bytes, (uint32_t)block_size, level, checksum_enabled, device, ZXC_OK, &S[(bi + 1) & 1]};
+            started = 1;
+            live = pthread_create(&th, NULL, comp_up_main, &up) == 0;
+            if (!live) comp_up_main(&up); /* (no thread: in series) */
+        }
+        TS(2);
+        rc = zxc_mi355x_synchronize(s->stream);
+        TS(3);
+        if (rc == ZXC_OK) rc = zxc_hip_memcpy_d2h_async(sizes + b0, s->d_sizes, (size_t)nbi * 4, s->stream);
+        if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(s->stream);
+        uint64_t total = 0;
+        if (rc == ZXC_OK) {
+            for (uint32_t i = 0; i < nbi; i++) {
+                if (sizes[b0 + i] > block_size + 64) { rc = ZXC_ERROR_CORRUPT_DATA; break; } /* (never trusted as a copy length) */
+                offs[i] = total;
+                total += sizes[b0 + i];
+            }
+            if (rc == ZXC_OK && (uint64_t)op + total + tail_need > (uint64_t)dst_capacity) rc = ZXC_ERROR_DST_TOO_SMALL;
+        }
+        TS(4);
+        if (rc == ZXC_OK) rc = zxc_hip_memcpy_h2d_async(s->d_offs, offs, (size_t)nbi * 8, s->stream);
+        if (rc == ZXC_OK)
+            rc = zxc_mi355x_gather_blocks_device(s->d_slots, (uint32_t)block_size, (const uint32_t*)s->d_sizes, (const uint64_t*)s->d_offs,
+                                                 s->d_out, nbi, s->stream);
+        if (rc == ZXC_OK) rc = zxc_hip_memcpy_d2h_async(dst + op, s->d_out, (size_t)total, s->stream);
+        if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(s->stream); /* (also: `offs` may be rewritten) */
+        if (rc == ZXC_OK && checksum_enabled) /* fold the block trailers in stream order (zxc_dispatch.c:754-759) */
+            for (uint32_t i = 0; i < nbi; i++)
+                global_hash = ((global_hash << 1) | (global_hash >> 31)) ^ rd32(dst + op + offs[i] + sizes[b0 + i] - 4);
+        if (rc == ZXC_OK) op += (size_t)total;
+        TS(5);
+        if (live) pthread_join(th, NULL);
+        TS(6);
+        if (dbg) fprintf(stderr, "[zxc_compress] batch %u: wait for its encode %.2f, sizes %.2f, offsets + gather + download %.2f, wait for the next upload %.2f ms\n", bi, MS(2, 3), MS(3, 4), MS(4, 5), MS(5, 6));
+        if (started && rc == ZXC_OK) rc = up.rc;
+    }
+    /* nothing of ours may still be running on the slots when they are freed */
+    for (int k = 0; k < 2; k++)
+        if (S[k].stream) (void)zxc_mi355x_synchronize(S[k].stream);
+    TS(6);
+    for (int k = 0; k < 2; k++) comp_slot_free(&S[k]);
+    free(offs);
+    TS(7);
+    if (dbg) fprintf(stderr, "[zxc_compress] release %.2f ms\n", MS(6, 7));
+#undef TS
+#undef MS
+    if (rc != ZXC_OK) return rc;
+    *op_io = op;
+    *hash_io = global_hash;
+    return ZXC_OK;
+}
+
 int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const size_t dst_capacity,
                      const zxc_compress_opts_t* opts) {
     uint8_t* dst = (uint8_t*)dst_v;
@@ -755,7 +887,18 @@ int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const 
     const uint32_t nb = (uint32_t)nb64;
     uint32_t* sizes = NULL;
     uint32_t global_hash = 0;
-    if (nb > 0) {
+    size_t batch_bytes = FRAME_BATCH_BYTES;
+    { const char* e = getenv("ZXC_MI355X_FRAME_BATCH_MIB"); if (e && atoi(e) >= 1 && atoi(e) <= 1024) batch_bytes = (size_t)atoi(e) << 20; }
+    const uint32_t batch_blocks = (uint32_t)(batch_bytes / block_size > 0 ? batch_bytes / block_size : 1);
+    if (nb > batch_blocks && !dict_size) { /* two batches or more: pipelined */
+        if (zxc_mi355x_device_count() <= 0) return ZXC_ERROR_GPU_UNAVAILABLE;
+        sizes = (uint32_t*)malloc((size_t)nb * sizeof(uint32_t));
+        if (!sizes) return ZXC_ERROR_MEMORY;
+        const size_t tail_need = BLK_HDR + (seekable ? zxc_seek_table_size(nb) : 0) + ZXC_FILE_FOOTER_SIZE;
+        const int rc = compress_batches((const uint8_t*)src, src_size, block_size, level, checksum_enabled, tail_need, dst, dst_capacity,
+                                        &op, sizes, nb, batch_blocks, &global_hash);
+        if (rc != ZXC_OK) { free(sizes); return rc; }
+    } else if (nb > 0) {
         if (zxc_mi355x_device_count() <= 0) return ZXC_ERROR_GPU_UNAVAILABLE;
         const uint32_t stride = zxc_mi355x_encode_slot_stride((uint32_t)block_size);
         sizes = (uint32_t*)malloc((size_t)nb * sizeof(uint32_t));
