@@ -804,8 +804,11 @@ static int compress_batches(const uint8_t* src, size_t src_size, size_t block_si
         TS(2);
         rc = zxc_mi355x_synchronize(s->stream);
         TS(3);
-        if (rc == ZXC_OK) rc = zxc_hip_memcpy_d2h_async(sizes + b0, s->d_sizes, (size_t)nbi * 4, s->stream);
-        if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(s->stream);
+        /* From here on this thread works on the default stream with synchronous calls: the runtime maps streams onto a few
+         * hardware queues, and when this slot's stream shares one with the other slot's, anything queued on it now would
+         * stand behind batch i + 1's upload and encode (measured inside a process that holds other streams: the 8 KiB of
+         * sizes took 4.7 ms, the call ran at one-shot speed). */
+        if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(sizes + b0, s->d_sizes, (size_t)nbi * 4);
         uint64_t total = 0;
         if (rc == ZXC_OK) {
             for (uint32_t i = 0; i < nbi; i++) {
@@ -816,12 +819,11 @@ static int compress_batches(const uint8_t* src, size_t src_size, size_t block_si
             if (rc == ZXC_OK && (uint64_t)op + total + tail_need > (uint64_t)dst_capacity) rc = ZXC_ERROR_DST_TOO_SMALL;
         }
         TS(4);
-        if (rc == ZXC_OK) rc = zxc_hip_memcpy_h2d_async(s->d_offs, offs, (size_t)nbi * 8, s->stream);
+        if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_h2d(s->d_offs, offs, (size_t)nbi * 8);
         if (rc == ZXC_OK)
             rc = zxc_mi355x_gather_blocks_device(s->d_slots, (uint32_t)block_size, (const uint32_t*)s->d_sizes, (const uint64_t*)s->d_offs,
-                                                 s->d_out, nbi, s->stream);
-        if (rc == ZXC_OK) rc = zxc_hip_memcpy_d2h_async(dst + op, s->d_out, (size_t)total, s->stream);
-        if (rc == ZXC_OK) rc = zxc_mi355x_synchronize(s->stream); /* (also: `offs` may be rewritten) */
+                                                 s->d_out, nbi, NULL);
+        if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(dst + op, s->d_out, (size_t)total); /* (ordered behind the gather, returns when the bytes are here) */
         if (rc == ZXC_OK && checksum_enabled) /* fold the block trailers in stream order (zxc_dispatch.c:754-759) */
             for (uint32_t i = 0; i < nbi; i++)
                 global_hash = ((global_hash << 1) | (global_hash >> 31)) ^ rd32(dst + op + offs[i] + sizes[b0 + i] - 4);
