@@ -396,3 +396,37 @@ def test_section_kernels_every_size_class_and_scratch_overflow_on_emulator(emu, 
         assert mixes, "no scratch size made the second workgroup overflow"
     finally:
         L.emu_set_pscratch_bytes(8 << 20)
+
+
+def test_encoder_parse_fuzz_on_emulator(emu, ref, oracle):
+    """The parse since round 4: every lane settles its own position (take / step 1 / step 2), a shuffle tells every match end where
+    the next match starts, the scalar loop hops. Phrase soups of ragged sizes put match starts, lazy steps and match ends on every
+    chunk-relative position (lane 62 / 63 look past the chunk, the block's last chunk is short): levels 1-4 (greedy, lazy 2, both
+    table geometries), 4 KiB and 64 KiB blocks, every archive decoded by the oracle, a sample by the reference."""
+    rng = random.Random(20260926)
+    words = [bytes(rng.getrandbits(8) for _ in range(rng.randint(3, 40))) for _ in range(24)]
+    for case in range(160):
+        n = rng.randint(70, 9000)
+        buf = bytearray()
+        while len(buf) < n:
+            r = rng.random()
+            if r < 0.70:
+                w = words[rng.randrange(len(words))]
+                buf += w[:rng.randint(1, len(w))]
+            elif r < 0.85:
+                buf += bytes(rng.getrandbits(8) for _ in range(rng.randint(1, 9)))
+            elif r < 0.95 and len(buf) > 8:
+                d = rng.randint(1, min(len(buf), 300)); k = rng.randint(5, 200)   # an overlapping copy
+                for _ in range(k):
+                    buf.append(buf[-d])
+            else:
+                buf += bytes([rng.getrandbits(8)]) * rng.randint(5, 150)
+        data = bytes(buf[:n])
+        level = 1 + case % 4
+        bs = 4096 if case % 3 else 65536
+        comp = emu.encode(data, level, bs, checksum=bool(case & 8))
+        rc, out = oracle.decompress(comp, len(data), checksum=bool(case & 8))
+        assert rc == len(data) and out == data, (case, level, bs, n, rc)
+        if case % 16 == 0:
+            rc, out = ref.decompress(comp, len(data), checksum=bool(case & 8))
+            assert rc == len(data) and out == data, ("reference decoder", case, level, n, rc)
