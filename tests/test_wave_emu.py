@@ -143,6 +143,14 @@ def test_optimal_parse_level6_on_emulator(emu, ref, oracle, synth_inputs):
     _enc_roundtrip(emu, ref, oracle, bytes(rng.getrandbits(8) for _ in range(70000)), 6)  # incompressible: literals only, RAW blocks
     _enc_roundtrip(emu, ref, oracle, (b"x" * 300 + bytes(range(256))) * 40, 6, 4096, checksum=True)
     _enc_roundtrip(emu, ref, oracle, (b"0123456789abcdef" * 37 + bytes(range(200))) * 400, 6, 262144)  # > OPT_MAX_BLOCK: the lazy parse
+    # matches longer than the DP's length cap (OPT_LCAP = 4080): the capped match must be continued where it ends (ADVICE r4:
+    # hiding the uncapped length left everything behind the cap as literals — zeros came out 78 x the reference's size)
+    unit = bytes(rng.getrandbits(8) for _ in range(20000))
+    for data in (bytes(131072), unit * 6):
+        z6 = _enc_roundtrip(emu, ref, oracle, data, 6)
+        z5 = _enc_roundtrip(emu, ref, oracle, data, 5)
+        zr = ref.compress(data, 6, 65536, True, False)
+        assert len(z6) <= len(z5) + 128 and len(z6) <= 1.02 * len(zr) + 128  # (a capped match costs ~3.5 bytes per 4080: 16 per 64 KiB block of zeros), (len(z6), len(z5), len(zr))
     text = synth_inputs["mixed_384k"][:131072]
     c6 = _enc_roundtrip(emu, ref, oracle, text, 6)
     c5 = _enc_roundtrip(emu, ref, oracle, text, 5)

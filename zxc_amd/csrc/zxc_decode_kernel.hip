@@ -1623,7 +1623,9 @@ zxc_order_scatter_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* 
     __syncthreads();
     if (threadIdx.x == 0) {
         // RLE scratch for the LEAN_RLE blocks of this workgroup: the same saturating cursor as below; no room -> the full kernel
-        bool rfit = true;
+        // (no scratch at all — first launch on a stream, >= 16 384 jobs, allocation failure: even a LEAN_RLE block without literals
+        //  must not stay here, the lean kernel tells such a block by its scratch pointer: reference accepts it, zxc_decompress.c:906-907)
+        bool rfit = rscratch_cap16 != 0u;
         wg_base[6] = 0;
         if (wg_cnt[7]) {
             atomicAdd(ctl + ZXC_DEV_CTL_RLE_WANTED, wg_cnt[6] + 1u);  // (+ 1: a launch whose RLE blocks all have n_lit == 0 still reads as "some")

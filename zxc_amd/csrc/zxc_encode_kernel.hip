@@ -466,7 +466,10 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
                 uint64_t lm = __ballot(rl >= OPT_LONG_SKIP);
                 while (lm) {  // a long match hides the positions inside it (ZXC_OPT_LONG_MATCH_SKIP, :956)
                     const int j = __builtin_ctzll(lm);
-                    const uint32_t su = cu + (uint32_t)j + (uint32_t)__builtin_amdgcn_readlane((int)rl, j) - 1u;
+                    // (only what the DP can cover: it relaxes lengths up to OPT_LCAP, so the position where a capped match ends is
+                    //  searched again and continues the match — hiding the uncapped length left everything behind + OPT_LCAP as literals)
+                    const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane((int)rl, j);
+                    const uint32_t su = cu + (uint32_t)j + (jl < OPT_LCAP ? jl : OPT_LCAP) - 1u;
                     skip_until = su > skip_until ? su : skip_until;
                     if (iA[u] > cu + (uint32_t)j && iA[u] < skip_until) rl = 0u;
                     const uint32_t upto = skip_until - cu;  // lanes below it are settled

@@ -812,7 +812,9 @@ static int compress_batches(const uint8_t* src, size_t src_size, size_t block_si
         uint64_t total = 0;
         if (rc == ZXC_OK) {
             for (uint32_t i = 0; i < nbi; i++) {
-                if (sizes[b0 + i] > block_size + 64) { rc = ZXC_ERROR_CORRUPT_DATA; break; } /* (never trusted as a copy length) */
+                /* (never trusted as a copy length, nor as the place of the trailer the global hash is folded from: a block is at
+                 *  least its 8-byte header, + 4 with checksums) */
+                if (sizes[b0 + i] > block_size + 64 || sizes[b0 + i] < 8u + (checksum_enabled ? 4u : 0u)) { rc = ZXC_ERROR_CORRUPT_DATA; break; }
                 offs[i] = total;
                 total += sizes[b0 + i];
             }
