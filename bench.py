@@ -359,17 +359,33 @@ def init_ranks(cpu=False):
     return rank, world, local, backend, dist
 
 
-def rank_partition(rank, world, tiles_per_gpu, block_size):
-    """The north-star partition: ONE corpus of world x tiles_per_gpu tiles = N blocks in one seek table; rank g
-    decodes the contiguous index range [g*N//G, (g+1)*N//G) (zxc_amd.shard.block_range, SURVEY.md §8(e))."""
+def corpus_tiles(world, tiles_per_gpu, total_tiles=0):
+    """Tiles of the ONE corpus: weak scaling = world x tiles_per_gpu (per-GPU work fixed); strong scaling (--scaling strong,
+    BASELINE configs[3] as worded: ONE 64 GiB corpus at 1/2/4/8 GPUs) = total_tiles whatever the world size."""
+    return total_tiles if total_tiles else world * tiles_per_gpu
+
+
+def rank_partition(rank, world, tiles_per_gpu, block_size, total_tiles=0):
+    """The north-star partition: ONE corpus of N blocks in one seek table; rank g decodes the contiguous index range
+    [g*N//G, (g+1)*N//G) (zxc_amd.shard.block_range, SURVEY.md §8(e))."""
     from zxc_amd import corpus, shard
-    n_total = world * tiles_per_gpu * (corpus.TILE_BYTES // block_size)
+    n_total = corpus_tiles(world, tiles_per_gpu, total_tiles) * (corpus.TILE_BYTES // block_size)
     first, last = shard.block_range(rank, world, n_total)
     return n_total, first, last
 
 
+PREP_CORE_S_PER_TILE = {1: 3.0, 2: 3.0, 3: 5.0, 4: 8.0, 5: 25.0, 6: 120.0, 7: 160.0}  # generation + reference encode of one 202 MiB tile, one core
+
+
+def prep_estimate_s(n_tiles, level, world):
+    """Rough wall time of this rank's input preparation (synthetic tiles + the reference encoder, untimed): every rank works on
+    1/world of the box's cores, at most 16 tiles at once (build_rank_corpus)."""
+    workers = max(1, min(16, n_tiles + 1, (os.cpu_count() or 1) // world // 2))
+    return -(-n_tiles // workers) * PREP_CORE_S_PER_TILE.get(level, 5.0)
+
+
 def decode_run(args, level, tiles, steps, warmup, comm, checksum=False, calib_launch=False, with_cpu_baseline=True,
-               cpu_budget_s=12.0):
+               cpu_budget_s=12.0, block_size=None):
     """One decode measurement: this rank's block range of ONE corpus of world x tiles tiles, `steps` timed launches
     bracketed by barrier + synchronize, every byte and status checked before and after. -> the result line on rank 0."""
     import multiprocessing as mp
@@ -379,10 +395,21 @@ def decode_run(args, level, tiles, steps, warmup, comm, checksum=False, calib_la
     # generator processes (numpy only; spawn keeps them free of torch state)
     pool = mp.get_context("spawn").Pool(max(1, min(48, (os.cpu_count() or 1) // world)))
     dev = torch.device("cuda", local)
-    bs = args.block_size
+    bs = block_size or args.block_size
+    strong = getattr(args, "scaling", "weak") == "strong"
+    total_tiles = (args.total_tiles or 8 * tiles) if strong else 0
+    all_tiles = corpus_tiles(world, tiles, total_tiles)
 
     # ---- workload: this rank's block range of the one corpus
-    n_total, first, last = rank_partition(rank, world, tiles, bs)
+    n_total, first, last = rank_partition(rank, world, tiles, bs, total_tiles)
+    from zxc_amd import corpus as _corpus
+    my_tiles = (last - 1) // (_corpus.TILE_BYTES // bs) - first // (_corpus.TILE_BYTES // bs) + 1 if last > first else 0
+    est = prep_estimate_s(my_tiles, level, world)
+    print(f"[bench] rank {rank}/{world}: blocks [{first}, {last}) of {n_total} ({my_tiles} tiles, level {level}, {bs >> 10} KiB blocks); "
+          f"input preparation (reference encoder, untimed) estimated at ~{est:.0f} s", file=sys.stderr, flush=True)
+    if est > args.max_prep_s:
+        raise SystemExit(f"bench.py: preparing {my_tiles} tiles per rank at level {level} would take ~{est:.0f} s (> --max-prep-s "
+                         f"{args.max_prep_s}): lower --tiles / --total-tiles or raise --max-prep-s")
     base_tiles = min(CPU_BASELINE_TILES, tiles) if (with_cpu_baseline and world == 1) else 0
     d_comp, my_sizes, d_want, hdr, eof, prep, tile0_comp = build_rank_corpus(first, last, level, bs, pool, dev, checksum, base_tiles)
     pool.close()
@@ -441,6 +468,9 @@ def decode_run(args, level, tiles, steps, warmup, comm, checksum=False, calib_la
     step()
     torch.cuda.synchronize()
     check("after timing")
+    # every rank's own numbers (an imbalance must be visible): control plane only, after the timed region
+    mine = {"rank": rank, "blocks": [int(first), int(last)], "decoded_bytes": out_bytes, "wall_s": round(wall, 6),
+            "GBs": round(out_bytes * steps / wall / 1e9, 2), "avg_launch_ms": round(float(np.mean(kern_ms)), 4), "prep_s": prep["prep_s"]}
     if world > 1:
         t = torch.tensor([wall, float(out_bytes)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         tmax = t.clone()
@@ -448,30 +478,36 @@ def decode_run(args, level, tiles, steps, warmup, comm, checksum=False, calib_la
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         wall = float(tmax[0].item())
         total_out = int(t[1].item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     else:
         total_out = out_bytes
+        per_rank = [mine]
     if rank != 0:
         return None
     avg_kernel_s = float(np.mean(kern_ms)) / 1e3
     value = total_out * steps / wall / 1e9
     achieved = algo_bytes / avg_kernel_s / 1e9
     cfg = "configs[4]" if level == 7 else "configs[1]" if level == 3 else f"configs[1] at level {level}"
-    if world > 1:
-        cfg = f"configs[3] ({world * tiles * 211943424 / 2**30:.1f} GiB corpus over {world} GPUs)"
-    traffic = profiled_traffic("decode_l%d" % level, tiles=tiles, block_size=bs) if not checksum else None
+    if bs != 65536:
+        cfg += f" at the reference's {'default' if bs == 524288 else 'maximum' if bs == 2097152 else 'other'} block size"
+    if world > 1 or strong:
+        cfg = f"configs[3] ({all_tiles * 211943424 / 2**30:.1f} GiB corpus over {world} GPUs, {'strong' if strong else 'weak'} scaling)"
+    traffic = profiled_traffic("decode_l%d" % level, tiles=tiles, block_size=bs) if not (checksum or strong) else None
     line = {
         "metric": f"seekable decode GB/s (level {level}, {bs >> 10} KiB independent blocks, HBM-resident in/out"
                   + (", per-block checksums verified on the device)" if checksum else ")"),
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-        "ms_per_step": round(wall / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(wall / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"{cfg}: ONE seekable corpus of {world * tiles} tiles x 211943424 B ({prep['source']}), "
+        "config": {"workload": f"{cfg}: ONE seekable corpus of {all_tiles} tiles x 211943424 B ({prep['source']}), "
                                f"level {level}, {bs >> 10} KiB blocks, {n_total} blocks in one seek table; rank g decodes "
                                f"blocks [g*N//G, (g+1)*N//G) (rank 0: [{first}, {last})), one wavefront per block",
                    "blocks_per_gpu": n_jobs, "decoded_bytes_per_gpu": out_bytes,
                    "compressed_bytes_per_gpu": algo_bytes - out_bytes,
                    "ratio": round(out_bytes / (algo_bytes - out_bytes), 3),
-                   "parallelism": f"seek-table block range x{world}, no collectives on the data path", "prep": prep},
+                   "parallelism": f"seek-table block range x{world}, no collectives on the data path", "prep": prep,
+                   "per_rank": per_rank},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "kernel": "zxc_decode_blocks_lean_kernel + zxc_decode_blocks_kernel (blocks with coded sections), side by side"
@@ -589,6 +625,41 @@ def host_api_run(args, dev):
     return res
 
 
+def configs0_run(args):
+    """BASELINE configs[0]: the CPU reference's own zxc_compress / zxc_decompress round trip of dickens-class text at level 3
+    (10 MB; the reference's default 512 KiB blocks, and one 2 MiB block for "single block") — the stated bit-exact baseline.
+    Timed on the host (reference, 1 thread); then the same archives through this library: the reference-written archive decoded
+    on the GPU == the text, the archive written by zxc_compress of this library decoded by the unmodified reference == the text."""
+    import zxc_amd
+    from zxc_amd import corpus
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    if not oracle_py.Ref.available():
+        return None
+    ref = oracle_py.Ref()
+    text = b"".join(corpus.gen_chunk(c) for c in corpus.enwik_chunks(16 << 20, seed=77))[:10_000_000]
+    res = {"text_bytes": len(text), "level": 3, "what": "reference zxc_compress / zxc_decompress on one host core (bit-exact baseline), and the "
+                                                        "same archives through libzxc_mi355x.so in both directions"}
+    for name, bs, n in (("default_512k_blocks", 524288, len(text)), ("single_2m_block", 2097152, 2097152)):
+        data = text[:n]
+        best_c = best_d = None
+        for _ in range(3):
+            t0 = time.perf_counter(); arc = ref.compress(data, 3, bs, False, False); dt = time.perf_counter() - t0
+            best_c = dt if best_c is None or dt < best_c else best_c
+            t0 = time.perf_counter(); rc, out = ref.decompress(arc, len(data)); dt = time.perf_counter() - t0
+            best_d = dt if best_d is None or dt < best_d else best_d
+            assert rc == len(data) and out == data
+        got = zxc_amd.decompress(arc)
+        assert got == data, "GPU decode of the reference-written archive differs"
+        ours = zxc_amd.compress(data, 3, bs, False)
+        rc, out = ref.decompress(ours, len(data))
+        assert rc == len(data) and out == data, "reference decoder rejects this library's archive"
+        res[name] = {"bytes": len(data), "block_size": bs, "ratio_reference": round(len(data) / len(arc), 3), "ratio_this_library": round(len(data) / len(ours), 3),
+                     "reference_compress_MBs_1t": round(len(data) / best_c / 1e6, 1), "reference_decompress_MBs_1t": round(len(data) / best_d / 1e6, 1),
+                     "gpu_decode_of_reference_archive": "bit-exact", "reference_decode_of_gpu_archive": "bit-exact"}
+    return res
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` with no launcher around it: start N ranks of this script through torch.distributed.run
     (one process per GPU, rendezvous on 127.0.0.1) and hand their exit code back — never a silent one-GPU run."""
@@ -615,7 +686,8 @@ def rehearse(args, comm):
     corpus.TILE_BYTES = 5 * 65536
     corpus.CHUNK_BYTES = 2 * 65536
     bs = 65536
-    n_total, first, last = rank_partition(rank, world, args.tiles, bs)
+    total_tiles = (args.total_tiles or 8 * args.tiles) if args.scaling == "strong" else 0
+    n_total, first, last = rank_partition(rank, world, args.tiles, bs, total_tiles)
     d_comp, my_sizes, d_want, hdr, eof, prep, _ = build_rank_corpus(first, last, args.level, bs, None, torch.device("cpu"))
     if world > 1:
         gathered = [None] * world
@@ -638,7 +710,7 @@ def rehearse(args, comm):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     if rank == 0:
         print(json.dumps({"metric": "rehearsal of the N-rank launch path on CPU tensors (no device launch, nothing timed)", "value": 0.0,
-                          "unit": "GB/s", "n_gpus": world, "rehearsal": True, "blocks_total": n_total, "blocks_rank0": [first, last],
+                          "unit": "GB/s", "n_gpus": world, "rehearsal": True, "scaling": args.scaling, "blocks_total": n_total, "blocks_rank0": [first, last],
                           "decoded_bytes_all_ranks": int(t.item()), "checker": "oracle decode of every rank's jobs == corpus"}))
 
 
@@ -666,6 +738,14 @@ def main():
                     help="decode = the headline metric (BASELINE.json configs[1]; --level 7 gives configs[4]); "
                          "encode = configs[2]: device match finder + serialiser over enwik-like text, GB/s of source")
     ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the N-rank launch path (gloo, no device launch)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): --tiles per GPU, the corpus grows with N; strong: ONE corpus of --total-tiles tiles (BASELINE "
+                         "configs[3] as worded: 64 GiB at 1/2/4/8 GPUs), rank g decodes its block range of it")
+    ap.add_argument("--total-tiles", type=int, default=0,
+                    help="--scaling strong: tiles of the one corpus (default 8 x --tiles = 328 tiles = 64.7 GiB decoded; N = 1 holds "
+                         "all of it: 69 GB out + 69 GB reference copy + 35 GB compressed of the 288 GB)")
+    ap.add_argument("--max-prep-s", type=float, default=float(os.environ.get("ZXC_BENCH_MAX_PREP_S", "1500")),
+                    help="refuse a run whose (untimed) input preparation is estimated above this many seconds per rank")
     args = ap.parse_args()
     if args.rehearse:
         os.environ.setdefault("ZXC_BENCH_BACKEND", "gloo")
@@ -700,6 +780,12 @@ def main():
                                            with_cpu_baseline=not args.no_cpu_baseline, cpu_budget_s=6.0)
                 sec["encode_l3"] = encode_run(args, 3, args.enc_mib, max(3, args.steps // 4), 1, comm, not args.no_cpu_baseline)
                 sec["host_api"] = host_api_run(args, torch.device("cuda", local))
+                # the block sizes the reference defaults to (512 KiB; maximum 2 MiB: include/zxc_constants.h:60-64 there): the SAME corpus
+                # bytes re-encoded by the reference at that block size, device-resident, one wavefront per block
+                for key, bsz in (("block_512k", 524288), ("block_2m", 2097152)):
+                    sec[key] = decode_run(args, 3, args.tiles, max(5, args.steps // 2), 2, comm, with_cpu_baseline=not args.no_cpu_baseline,
+                                          cpu_budget_s=4.0, block_size=bsz)
+                sec["configs0_cpu_reference"] = configs0_run(args)
                 line["secondary"] = sec
         if rank == 0:
             print(json.dumps(line))

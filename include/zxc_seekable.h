@@ -32,7 +32,10 @@ ZXC_EXPORT uint32_t zxc_seekable_get_block_comp_size(const zxc_seekable* s, cons
 ZXC_EXPORT uint32_t zxc_seekable_get_block_decomp_size(const zxc_seekable* s, const uint32_t block_idx);
 
 /* reference include/zxc_seekable.h:191 / :214 — returns len or a negative zxc_error_t.
- * n_threads is accepted for ABI compatibility and ignored. */
+ * _mt: a block is a wavefront's work here, so host threads add nothing on ONE device and by default the call stays on the calling
+ * thread's current device whatever n_threads says (a rank of a one-process-per-GPU job never touches the other ranks' GPUs).
+ * With ZXC_MI355X_DEVICES=<ordinals, comma-separated; one may repeat> the covered blocks are cut into min(n_threads, listed
+ * devices) contiguous parts (n_threads == 0: all listed), one host thread + stream + staging arena per part (zxc_host.c). */
 ZXC_EXPORT int64_t zxc_seekable_decompress_range(zxc_seekable* s, void* dst, const size_t dst_capacity,
                                                  const uint64_t offset, const size_t len);
 ZXC_EXPORT int64_t zxc_seekable_decompress_range_mt(zxc_seekable* s, void* dst, const size_t dst_capacity,

@@ -182,3 +182,17 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     """Under a launcher WORLD_SIZE must equal --gpus: a mismatch exits non-zero instead of printing an n_gpus = 1 line."""
     rc, lines, err = _run_bench(["--gpus", "8", "--rehearse"], env_extra={"WORLD_SIZE": "1", "RANK": "0"}, drop=())
     assert rc != 0 and not lines and "--gpus 8" in err
+
+
+def test_bench_strong_scaling_is_one_fixed_corpus(ref):
+    """--scaling strong (BASELINE configs[3] as worded: ONE corpus at 1/2/4/8 GPUs): the corpus has --total-tiles tiles whatever
+    the world size; 2 ranks split the same 20 blocks 1 rank decodes alone; the prep-time guard refuses what it estimates too long."""
+    import bench
+    assert bench.corpus_tiles(8, 41) == 328 and bench.corpus_tiles(8, 41, 328) == 328 and bench.corpus_tiles(1, 41, 328) == 328
+    rc, lines, err = _run_bench(["--gpus", "2", "--rehearse", "--scaling", "strong", "--total-tiles", "4", "--tiles", "1"])
+    assert rc == 0, err[-2000:]
+    assert lines[0]["n_gpus"] == 2 and lines[0]["scaling"] == "strong" and lines[0]["blocks_total"] == 20 and lines[0]["blocks_rank0"] == [0, 10]
+    rc1, lines1, err1 = _run_bench(["--gpus", "1", "--rehearse", "--scaling", "strong", "--total-tiles", "4", "--tiles", "1"])
+    assert rc1 == 0 and lines1[0]["blocks_total"] == 20 and lines1[0]["blocks_rank0"] == [0, 20], err1[-2000:]
+    assert lines1[0]["decoded_bytes_all_ranks"] == lines[0]["decoded_bytes_all_ranks"] == 20 * 65536
+    assert bench.prep_estimate_s(41, 3, 8) < bench.prep_estimate_s(328, 3, 1) < bench.prep_estimate_s(328, 7, 1)

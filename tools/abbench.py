@@ -81,7 +81,7 @@ elif __name__ == "__main__":
         d_comp, sizes, d_want, *_ = bench.build_rank_corpus(0, tiles * corpus.TILE_BLOCKS, level, 65536, pool, torch.device("cpu"))
     np.save(f"{TMP}/comp.npy", d_comp.numpy()); np.save(f"{TMP}/sizes.npy", sizes); np.save(f"{TMP}/want.npy", d_want.numpy())
     for lib in sys.argv[1:]:
-        env = dict(os.environ); env["ZXC_LIB_VARIANT"] = lib
+        env = dict(os.environ); env["ZXC_LIB_VARIANT"] = lib; env["ZXC_TOOLS_AB"] = "1"
         try:  # (AB_TIMEOUT: a hung variant must not take the GPU call with it)
             subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=env, timeout=float(os.environ.get("AB_TIMEOUT", "240")))
         except subprocess.TimeoutExpired:

@@ -2,7 +2,7 @@
 """Per-block wall time inside one launch of the bench workload (needs the EXP_TIMES build:
 tools/build_variant.sh times -DEXP_TIMES). Prints the duration distribution and the residency timeline."""
 import os, sys
-os.environ["ZXC_LIB_VARIANT"] = os.environ.get("ZXC_LIB_VARIANT", "libzxc_times.so")
+os.environ["ZXC_LIB_VARIANT"] = os.environ.get("ZXC_LIB_VARIANT", "libzxc_times.so"); os.environ["ZXC_TOOLS_AB"] = "1"
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -9,7 +9,7 @@ name=$1; filter=$2; shift; shift
 B=build/var_$name; mkdir -p $B
 LLVM=/opt/rocm/lib/llvm/bin
 HIPCC=/opt/rocm/bin/hipcc
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-function"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-function -DZXC_EXPERIMENT"
 $HIPCC $F "$@" --cuda-device-only -S zxc_decode_kernel.hip -o $B/dk_dev.s
 $filter < $B/dk_dev.s > $B/dk_dev_f.s
 $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $B/dk_dev_f.s -o $B/dk_dev.o

@@ -31,7 +31,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     print(f"{os.environ.get('ZXC_LIB_VARIANT','libzxc_mi355x.so'):24s} L{level}: {n>>20} MiB in {best:8.2f} ms = {n/best/1e6:7.1f} GB/s  ratio {n/int(d_sizes.sum().item()):.4f} sizes-sha {h}", flush=True)
 elif __name__ == "__main__":
     for lib in sys.argv[1:]:
-        env = dict(os.environ); env["ZXC_LIB_VARIANT"] = lib
+        env = dict(os.environ); env["ZXC_LIB_VARIANT"] = lib; env["ZXC_TOOLS_AB"] = "1"
         try:
             subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=env, timeout=float(os.environ.get("AB_TIMEOUT", "120")))
         except subprocess.TimeoutExpired:

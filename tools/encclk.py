@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where a chunk's wall time goes in the encoder (GPU box): ZXC_LIB_VARIANT=libzxc_clk.so python tools/encclk.py  (ENC_LEVEL, default 3)
+"""Where a chunk's wall time goes in the encoder (GPU box): ZXC_TOOLS_AB=1 ZXC_LIB_VARIANT=libzxc_clk.so python tools/encclk.py  (ENC_LEVEL, default 3)
 Needs the -DEXP_ENC_CLOCKS build of the encode kernel and the shim (zxc_encode_kernel.hip: ENC_T). One launch over 256 MiB of text;
 prints every phase's share of the summed per-wave clocks and the clocks per chunk of 64 positions."""
 import os, sys

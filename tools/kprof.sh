@@ -14,8 +14,8 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD S
            "TA_TA_BUSY_sum TA_FLAT_WAVEFRONTS_sum" "TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TA_TCP_STATE_READ_sum" \
            "TD_TD_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1)); [ $i -gt $maxsets ] && break
-  ZXC_LIB_VARIANT=$lib timeout -k 5 120 rocprofv3 --pmc $set -d $R/gpurun_out/${tag}_kp$i -o p --output-format csv -- python $R/tools/abbench.py --one > $R/gpurun_out/${tag}_kp$i.log 2>&1
+  ZXC_TOOLS_AB=1 ZXC_LIB_VARIANT=$lib timeout -k 5 120 rocprofv3 --pmc $set -d $R/gpurun_out/${tag}_kp$i -o p --output-format csv -- python $R/tools/abbench.py --one > $R/gpurun_out/${tag}_kp$i.log 2>&1
 done
-[ $maxsets -ge 99 ] && ZXC_LIB_VARIANT=$lib timeout -k 5 120 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_kpt -o p --output-format csv -- python $R/tools/abbench.py --one > $R/gpurun_out/${tag}_kpt.log 2>&1
+[ $maxsets -ge 99 ] && ZXC_TOOLS_AB=1 ZXC_LIB_VARIANT=$lib timeout -k 5 120 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_kpt -o p --output-format csv -- python $R/tools/abbench.py --one > $R/gpurun_out/${tag}_kpt.log 2>&1
 python $R/tools/kprof_summary.py $tag $kern > $R/gpurun_out/${tag}_kprof.txt 2>&1
 cat $R/gpurun_out/${tag}_kprof.txt

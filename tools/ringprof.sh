@@ -7,8 +7,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 export AB_TILES=${AB_TILES:-10} AB_TIMEOUT=100
 timeout 400 python $R/tools/abbench.py libzxc_mi355x.so libzxc_allnear.so libzxc_r4kw4.so libzxc_r8kw4.so libzxc_r4kw4an.so libzxc_r8kw4an.so libzxc_mi355x.so 2>&1 | grep "GB/s\|TIMEOUT" > $R/gpurun_out/r4e_ring_times.log
 for v in r4kw4 r8kw4; do
-  ZXC_LIB_VARIANT=libzxc_$v.so timeout 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES -d $R/gpurun_out/r4e_sq_$v -o s --output-format csv -- python $R/tools/abbench.py --one > $R/gpurun_out/r4e_sq_$v.log 2>&1
-  ZXC_LIB_VARIANT=libzxc_$v.so timeout 150 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS -d $R/gpurun_out/r4e_mem_$v -o m --output-format csv -- python $R/tools/abbench.py --one > $R/gpurun_out/r4e_mem_$v.log 2>&1
+  ZXC_TOOLS_AB=1 ZXC_LIB_VARIANT=libzxc_$v.so timeout 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES -d $R/gpurun_out/r4e_sq_$v -o s --output-format csv -- python $R/tools/abbench.py --one > $R/gpurun_out/r4e_sq_$v.log 2>&1
+  ZXC_TOOLS_AB=1 ZXC_LIB_VARIANT=libzxc_$v.so timeout 150 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS -d $R/gpurun_out/r4e_mem_$v -o m --output-format csv -- python $R/tools/abbench.py --one > $R/gpurun_out/r4e_mem_$v.log 2>&1
 done
 cat $R/gpurun_out/r4e_ring_times.log
 python3 - <<'PY'

@@ -40,7 +40,12 @@ class _Reader(C.Structure):  # zxc_reader_t, include/zxc_seekable.h
 
 
 def lib_path():
-    return os.path.join(_HERE, os.environ.get("ZXC_LIB_VARIANT", "libzxc_mi355x.so"))  # variant: A/B builds for tools/
+    # The product library, always — unless a development harness under tools/ asks for an A/B build on purpose: both
+    # ZXC_TOOLS_AB=1 and ZXC_LIB_VARIANT=<file> must be set (a stray ZXC_LIB_VARIANT alone is ignored: experiment builds may
+    # produce wrong output by design, zxc_amd/csrc/zxc_experiments.h).
+    if os.environ.get("ZXC_TOOLS_AB") == "1" and os.environ.get("ZXC_LIB_VARIANT"):
+        return os.path.join(_HERE, os.environ["ZXC_LIB_VARIANT"])
+    return os.path.join(_HERE, "libzxc_mi355x.so")
 
 
 def lib():

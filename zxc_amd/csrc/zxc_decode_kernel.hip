@@ -30,6 +30,7 @@
 // (rle_expand below, zxc_pivco.inc); checksums by zxc_rapidhash.inc; a dictionary prefix is a
 // template variant. Launch order: heaviest blocks first (zxc_order_* kernels at the end).
 // Integer byte work: no MFMA. Bound: HBM (compressed bytes in + decoded bytes out).
+#include "zxc_experiments.h"  // (first: the gate in front of every experiment switch)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

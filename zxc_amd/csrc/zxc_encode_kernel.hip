@@ -32,6 +32,7 @@
 // sufficient length, lazy probes: table at the bottom); levels 6-7 code the literal section (7: and the token
 // section) with PivCo (zxc_pivco_encode.inc). Output is a valid v8
 // block, round-trip-checked by tests/ against the unmodified reference decoder; archive bytes are deterministic.
+#include "zxc_experiments.h"  // (first: the gate in front of every experiment switch)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -884,6 +885,38 @@ zxc_prepend_dict_kernel(const uint8_t* __restrict__ src, uint64_t src_size, uint
     const uint32_t n = remain < block_size ? (uint32_t)remain : block_size;
     const uint8_t* s = src + (uint64_t)b * block_size;
     for (uint32_t o = lane; o < n; o += 64u) w[dict_size + o] = s[o];
+}
+
+// offsets[b] = sizes[0] + ... + sizes[b - 1] (one workgroup; a piece of the host API's pipeline is at most a few thousand blocks):
+// the compaction below can then follow the encode on its stream without a round trip through the host. Sizes are clamped to
+// max_size in place (the encoder never writes more: the host checks the sizes it reads back, this keeps the device in bounds).
+extern "C" __global__ void __launch_bounds__(256)
+zxc_block_offsets_kernel(uint32_t* __restrict__ sizes, uint64_t* __restrict__ offsets, uint32_t n_blocks, uint32_t max_size) {
+    __shared__ uint32_t part[256];
+    __shared__ uint64_t carry;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < n_blocks; c0 += 256u) {
+        const uint32_t b = c0 + t;
+        uint32_t v = 0;
+        if (b < n_blocks) {
+            v = sizes[b];
+            if (v > max_size) { v = max_size; sizes[b] = v; }
+        }
+        part[t] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < 256u; d <<= 1) {  // inclusive scan of the chunk
+            const uint32_t add = t >= d ? part[t - d] : 0u;
+            __syncthreads();
+            part[t] += add;
+            __syncthreads();
+        }
+        if (b < n_blocks) offsets[b] = carry + (uint64_t)(part[t] - v);
+        __syncthreads();
+        if (t == 255u) carry += part[255];
+        __syncthreads();
+    }
 }
 
 // Compaction: block b's bytes [slot, slot+sizes[b]) -> out + offsets[b] (+ optional 4-byte trailer gap).

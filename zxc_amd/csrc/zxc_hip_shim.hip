@@ -1,6 +1,7 @@
 // zxc_hip_shim.hip — the only C <-> HIP crossing of libzxc_mi355x.so.
 // extern "C" entry points declared in include/zxc_mi355x.h; host C code
 // (zxc_host.c) and external callers use plain pointers and sizes only.
+#include "zxc_experiments.h"  // (first: the gate in front of every experiment switch)
 #include <hip/hip_runtime.h>
 #include <pthread.h>
 #include <stdint.h>
@@ -66,6 +67,7 @@ ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l4)
 ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l57)
 extern "C" __global__ void zxc_prepend_dict_kernel(const uint8_t* src, uint64_t src_size, uint32_t block_size, const uint8_t* dict,
                                                    uint32_t dict_size, uint8_t* work, uint32_t n_blocks);
+extern "C" __global__ void zxc_block_offsets_kernel(uint32_t* sizes, uint64_t* offsets, uint32_t n_blocks, uint32_t max_size);
 extern "C" __global__ void zxc_gather_blocks_kernel(const uint8_t* slots, uint32_t slot_stride, const uint32_t* sizes,
                                                     const uint64_t* offsets, uint8_t* out, uint32_t n_blocks);
 
@@ -75,7 +77,7 @@ extern "C" __global__ void zxc_gather_blocks_kernel(const uint8_t* slots, uint32
 #ifndef ZXC_RLE_LEAN_MAX_JOBS
 #define ZXC_RLE_LEAN_MAX_JOBS 16384u
 #endif
-#define ZXC_ORDER_STREAMS 8
+#define ZXC_ORDER_STREAMS 16
 #define ZXC_POOLS 10 /* block_size_log2 12..21 */
 static struct {
     /* One scratch pool per block size: slot stride and slot count are functions of block_size only, so
@@ -170,6 +172,28 @@ int zxc_hip_memcpy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void*
     if (bytes == 0) return ZXC_OK;
     return hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
 }
+
+/* internal to the library (hidden): what the host API's piece pipeline needs besides streams (zxc_host.c) — an event behind a
+ * piece's launch, and pinned host memory for its block statuses (a stream-ordered copy into it needs no staging and no wait) */
+int zxc_hip_event_create(void** ev_out) {
+    hipEvent_t e = NULL;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;
+    *ev_out = (void*)e;
+    return ZXC_OK;
+}
+void zxc_hip_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+int zxc_hip_event_record(void* ev, void* stream) {
+    return hipEventRecord((hipEvent_t)ev, (hipStream_t)stream) == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
+}
+int zxc_hip_event_synchronize(void* ev) {
+    return hipEventSynchronize((hipEvent_t)ev) == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
+}
+void* zxc_hip_host_alloc(size_t bytes) {
+    void* p = NULL;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) return NULL;
+    return p;
+}
+void zxc_hip_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 extern "C" void zxc_host_release_arenas(void);
 /* Gives back the device memory this library keeps between calls: the host API's staging arenas (those nobody is using)
@@ -278,7 +302,12 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
         for (int i = 0; i < ZXC_ORDER_STREAMS; i++)
             if (g_dev[dev].ord[i].used && g_dev[dev].ord[i].stream == stream) k = i;
         for (int i = 0; k < 0 && i < ZXC_ORDER_STREAMS; i++)
-            if (!g_dev[dev].ord[i].used) { k = i; g_dev[dev].ord[i].used = 1; g_dev[dev].ord[i].stream = stream; }
+            if (!g_dev[dev].ord[i].used) {
+                k = i; g_dev[dev].ord[i].used = 1; g_dev[dev].ord[i].stream = stream;
+                // a slot that changes owner forgets what its previous owner's launches found: the new stream's first launch takes
+                // the full plan like any first launch, instead of a plan and scratch sizes inherited from an unrelated caller
+                if (g_dev[dev].ord[i].hint) { g_dev[dev].ord[i].hint[0] = 0xFFFFFFFFu; g_dev[dev].ord[i].hint[1] = 0u; }
+            }
         if (k >= 0) {  // (more distinct streams than buffers: one kernel in plain order, still correct)
             auto& o = g_dev[dev].ord[k];
             // u32 words: [128 histogram + cursors | list: count, next, n entries | order[n] | ctl (zxc_dev.h) | PRE job indices[n] |
@@ -550,6 +579,15 @@ int zxc_mi355x_gather_blocks_device(const void* d_slots, uint32_t block_size, co
     if (!d_slots || !d_sizes || !d_offsets || !d_out) return ZXC_ERROR_NULL_INPUT;
     hipLaunchKernelGGL(zxc_gather_blocks_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_slots,
                        zxc_mi355x_encode_slot_stride(block_size), d_sizes, d_offsets, (uint8_t*)d_out, n_blocks);
+    return hipGetLastError() == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
+}
+
+/* internal to the library (hidden): offsets of a piece's blocks in its compacted output, computed where the sizes are (zxc_host.c:
+ * the compaction follows the encode on its stream) */
+int zxc_hip_block_offsets(uint32_t* d_sizes, uint64_t* d_offsets, uint32_t n_blocks, uint32_t max_size, void* stream) {
+    if (n_blocks == 0) return ZXC_OK;
+    if (!d_sizes || !d_offsets) return ZXC_ERROR_NULL_INPUT;
+    hipLaunchKernelGGL(zxc_block_offsets_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d_sizes, d_offsets, n_blocks, max_size);
     return hipGetLastError() == hipSuccess ? ZXC_OK : ZXC_ERROR_GPU_UNAVAILABLE;
 }
 

@@ -27,7 +27,6 @@
 #define BLK_HDR 8
 #define TAIL_PAD 2112u /* ZXC_DECOMPRESS_TAIL_PAD, src/lib/zxc_internal.h:341 */
 #define HOST_BATCH_BYTES ((size_t)256 << 20) /* output slots per launch of the host Buffer API */
-#define FRAME_BATCH_BYTES ((size_t)128 << 20) /* zxc_decompress: two batches in flight (upload + launch of one beside the download of the other) */
 enum { BLK_RAW = 0, BLK_GLO = 1, BLK_GHI = 2, BLK_SEK = 254, BLK_EOF = 255 };
 
 static uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
@@ -277,6 +276,13 @@ int zxc_hip_stream_create(void** stream_out);
 void zxc_hip_stream_destroy(void* stream);
 int zxc_hip_memcpy_h2d_async(void* d_dst, const void* h_src, size_t bytes, void* stream);
 int zxc_hip_memcpy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void* stream);
+int zxc_hip_event_create(void** ev_out);
+void zxc_hip_event_destroy(void* ev);
+int zxc_hip_event_record(void* ev, void* stream);
+int zxc_hip_event_synchronize(void* ev);
+int zxc_hip_block_offsets(uint32_t* d_sizes, uint64_t* d_offsets, uint32_t n_blocks, uint32_t max_size, void* stream);
+void* zxc_hip_host_alloc(size_t bytes);
+void zxc_hip_host_free(void* p);
 
 /* Staging arenas: the device buffers of the host API live across calls (grown on demand), so a call costs its copies
  * and its launch, not four hipMalloc + hipFree (which synchronise the device). One call at a time uses an arena; its
@@ -286,13 +292,17 @@ int zxc_hip_memcpy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void*
  * stays within a few hundred MiB; a buffer that grew beyond ARENA_KEEP_MAX is given back when the call ends, and
  * zxc_mi355x_release_cached() frees everything that is not in use. */
 typedef struct { void* p; size_t cap; } dbuf_t;
-enum { AR_COMP = 0, AR_JOBS, AR_OUT, AR_STATUS, AR_DICT, AR_N };
+enum { AR_COMP = 0, AR_JOBS, AR_OUT, AR_STATUS, AR_DICT, AR_SLOTS, AR_N }; /* (AR_SLOTS: the encoder's per-block output slots) */
 typedef struct {
     pthread_mutex_t mu;
     dbuf_t buf[AR_N];
+    int32_t* h_st;   /* pinned host memory for a piece's block statuses (the piece pipeline below) */
+    size_t h_st_cap;
+    void* ev;        /* event recorded behind a piece's launch + status copy */
+    void* stream;    /* the stream this arena's pieces run on (created once: creating and destroying streams costs a call 0.3-0.5 ms) */
 } arena_t;
 #define HOST_MAX_DEVICES 16
-#define ARENA_SUBS 4
+#define ARENA_SUBS 8
 #define ARENA_KEEP_MAX ((size_t)768 << 20)
 static arena_t g_arena[HOST_MAX_DEVICES][ARENA_SUBS];
 static pthread_once_t g_arena_once = PTHREAD_ONCE_INIT;
@@ -322,8 +332,13 @@ void zxc_host_release_arenas(void) {
             if (pthread_mutex_trylock(&a->mu) != 0) continue; /* in use: its call trims it when it ends */
             int any = 0;
             for (int w = 0; w < AR_N; w++) any |= a->buf[w].p != NULL;
-            if (any && zxc_mi355x_set_device(dev) == ZXC_OK)
+            any |= a->h_st != NULL || a->ev != NULL || a->stream != NULL;
+            if (any && zxc_mi355x_set_device(dev) == ZXC_OK) {
                 for (int w = 0; w < AR_N; w++) { zxc_mi355x_free(a->buf[w].p); a->buf[w].p = NULL; a->buf[w].cap = 0; }
+                zxc_hip_host_free(a->h_st); a->h_st = NULL; a->h_st_cap = 0;
+                zxc_hip_event_destroy(a->ev); a->ev = NULL;
+                zxc_hip_stream_destroy(a->stream); a->stream = NULL;
+            }
             pthread_mutex_unlock(&a->mu);
         }
     if (cur >= 0) (void)zxc_mi355x_set_device(cur);
@@ -357,14 +372,6 @@ static void dev_bufs_free(dev_bufs_t* b) {
         pthread_mutex_unlock(&a->mu);
     }
 }
-/* decoded bytes of the batch back to the host, on the batch's stream */
-static int dev_bufs_read(const dev_bufs_t* b, void* h_dst, size_t d_off, size_t bytes) {
-    if (bytes == 0) return ZXC_OK;
-    if (!b->stream) return zxc_mi355x_memcpy_d2h(h_dst, (const uint8_t*)b->d_out + d_off, bytes);
-    const int rc = zxc_hip_memcpy_d2h_async(h_dst, (const uint8_t*)b->d_out + d_off, bytes, b->stream);
-    return rc == ZXC_OK ? zxc_mi355x_synchronize(b->stream) : rc;
-}
-
 /* Stage 1 of a batch: take the arena (dev, sub), reserve its buffers and upload the compressed bytes, the job table and the
  * dictionary. `stream` NULL: plain (synchronous) copies; else copies on that stream, complete when this returns. On failure the
  * arena is released. The two stages are separate so that zxc_decompress can upload batch i+1 from a helper thread while batch i's
@@ -443,33 +450,440 @@ static int run_jobs(const uint8_t* h_comp, size_t comp_bytes, const zxc_dev_job_
     return run_jobs_cap(h_comp, comp_bytes, jobs, n, out_bytes, block_size, 0u, verify_trailer, h_status, b, dr);
 }
 
-/* ------------------------------------------------------------ zxc_decompress */
+/* ------------------------------------------------------------ the piece pipeline */
+/* zxc_decompress and the seekable range calls move their blocks through the device in PIECES, three stages in flight. Two
+ * producer threads take turns asking the call's SOURCE for the next piece (a run of blocks: their compressed span on the host + a
+ * job table); each uploads its piece and enqueues its launch and the copy of its statuses on its own stream — a producer never
+ * waits for the device, and while one is uploading the other already walks and uploads the piece behind it (the runtime's pageable
+ * upload path moves ~25-40 GB/s per thread on this box, half the link). The calling thread waits for piece i's event and hands it
+ * to the call's SINK, which checks the statuses in stream order (first failing block wins, like the reference's sequential loops)
+ * and copies what the caller wants of the piece's output back. PCIe carries both directions at once and the launches (0.3-0.6 ms
+ * from enqueue to done whatever the piece's size: one round of wavefronts) hide under the copies: a call is bounded by its
+ * download (round 4: upload + launch of piece i+1 were one helper-thread job with a join behind every piece, the range call strictly
+ * serial: 45 / 33 GB/s of a link that carries 56 GB/s one way, 49 each way at once — profiles/r5a_*, r5d_*). Pieces ramp up
+ * (4, 8, 16, 32 MiB of output) so that the first download starts early. Device memory: one staging arena per slot in flight (up to
+ * PIPE_SLOTS, whatever is free: a caller never WAITS for a second arena while holding one; with one arena, or for a frame of one
+ * piece, the same steps run in series on the calling thread). */
+#define PIPE_SLOTS 6        /* the most a call holds (zxc_compress); the decode calls ask for PIPE_DECODE_SLOTS */
+#define PIPE_DECODE_SLOTS 4
+#define PIPE_PRODUCERS 2
+#define PIPE_FIRST_BYTES ((size_t)4 << 20)
+#define PIPE_PIECE_BYTES ((size_t)32 << 20)
+#define PIPE_IRREGULAR 1 /* a sink's verdict: stop here, the caller takes this piece another way */
+
 typedef struct {
-    const uint8_t* h_comp;
+    const uint8_t* h_comp;   /* host span of the piece's blocks */
     size_t comp_bytes;
-    const zxc_dev_job_t* jobs;
+    zxc_dev_job_t* jobs;     /* (the slot's array, max_blocks entries) comp_off relative to h_comp, out_off = the block's slot in the piece's output */
     uint32_t n;
     size_t out_bytes;
-    dev_bufs_t* b;
-    const dict_ref_t* dr;
-    int sub;
-    void* stream;
-    arena_t* arena; /* locked by the thread that started the helper */
-    int device, rc;
-    uint32_t block_size; /* the launch over the uploaded batch, on the helper's stream, and its statuses */
+    uint64_t cookie[6];      /* source -> sink */
+    uint8_t* stage;          /* host staging a source may use (reader callbacks), kept by the slot across pieces */
+    size_t stage_cap;
+} pipe_piece_t;
+typedef int (*pipe_source_fn)(void* ctx, uint32_t max_blocks, pipe_piece_t* p); /* 1: a piece, 0: no more, < 0: error */
+typedef int (*pipe_sink_fn)(void* ctx, const pipe_piece_t* p, const int32_t* st, const dev_bufs_t* b); /* (st: the piece's pinned status words) 0: go on, else: stop with it */
+
+typedef struct {
+    arena_t* a;
+    dev_bufs_t b;
+    pipe_piece_t p;
+    int rc;
+    int dict_up;       /* the dictionary is in this slot's arena */
+    uint64_t ready;    /* i + 1 once piece i sits enqueued (or failed: rc) in this slot */
+} pipe_slot_t;
+
+struct pipe_s;
+typedef int (*pipe_enqueue_fn)(struct pipe_s* e, pipe_slot_t* s, void* stream); /* a call's own upload + launch (NULL: the block decode below) */
+typedef struct pipe_s {
+    pipe_source_fn source;
+    void* source_ctx;
+    pipe_enqueue_fn enqueue;
+    void* enqueue_ctx;
+    uint32_t block_size;
     int verify;
-    int32_t* st;
-} host_upload_t;
-static void* host_upload_main(void* arg) {
-    host_upload_t* u = (host_upload_t*)arg;
-    u->rc = zxc_mi355x_set_device(u->device);
-    if (u->rc == ZXC_OK) u->rc = jobs_upload(u->h_comp, u->comp_bytes, u->jobs, u->n, u->out_bytes, u->b, u->dr, u->sub, u->stream, u->arena);
-    if (u->rc == ZXC_OK) { /* (jobs_execute releases the arena when it fails: not ours to release here — keep the handle for the caller) */
-        dev_bufs_t tmp = *u->b;
-        tmp.held = NULL;
-        u->rc = jobs_execute(&tmp, u->n, u->block_size, 0u, u->verify, u->st, u->dr, u->stream);
+    const dict_ref_t* dr;
+    uint32_t first_blocks, max_blocks, cap_blocks;
+    size_t cap_comp, cap_out; /* what a slot reserves up front (no buffer grows while pieces are in flight) */
+    int device, k;
+    int producers;                /* (piece i is uploaded and launched on the stream of its slot's arena) */
+    pipe_slot_t slot[PIPE_SLOTS];
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    pthread_mutex_t src_mu;       /* the source is asked for one piece at a time, in order */
+    uint64_t next, consumed;      /* pieces handed out by the source / taken by the sink */
+    int src_done, stop;
+} pipe_t;
+
+static double pipe_now_ms(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec * 1e3 + (double)t.tv_nsec * 1e-6;
+}
+#define PIPE_DBG_MAX 64
+typedef struct { double src0, up0, up1, launched, ready, sunk; uint32_t n; size_t comp, out; } pipe_dbg_t;
+static pipe_dbg_t* g_pipe_dbg = NULL; /* ZXC_MI355X_DEBUG_TIMES=1: one caller at a time, a timeline of the pieces on stderr */
+
+static uint32_t pipe_piece_blocks(const pipe_t* e, uint64_t i) { /* the ramp: 4, 8, 16, ... MiB of output up to the piece size */
+    uint32_t want = e->first_blocks;
+    for (uint64_t r = 0; r < i && want < e->max_blocks; r++) want <<= 1;
+    return want > e->max_blocks ? e->max_blocks : want;
+}
+
+/* piece i, already described by the source in its slot: upload, enqueue launch + status copy + event on `stream`. ZXC_OK or an error */
+static int pipe_enqueue(pipe_t* e, uint64_t i) {
+    pipe_slot_t* s = &e->slot[i % (uint64_t)e->k];
+    void* stream = s->a->stream;
+    pipe_dbg_t* dbg = (g_pipe_dbg && i < PIPE_DBG_MAX) ? &g_pipe_dbg[i] : NULL;
+    if (dbg) { dbg->up0 = pipe_now_ms(); dbg->n = s->p.n; dbg->comp = s->p.comp_bytes; dbg->out = s->p.out_bytes; }
+    arena_t* a = s->a;
+    const uint32_t n = s->p.n;
+    dev_bufs_t* b = &s->b;
+    memset(b, 0, sizeof *b);
+    b->stream = stream;
+    if (a->h_st_cap < (size_t)e->max_blocks * sizeof(int32_t)) {
+        zxc_hip_host_free(a->h_st);
+        a->h_st_cap = 0;
+        a->h_st = (int32_t*)zxc_hip_host_alloc((size_t)e->max_blocks * sizeof(int32_t));
+        if (a->h_st) a->h_st_cap = (size_t)e->max_blocks * sizeof(int32_t);
+    }
+    if (!a->ev && zxc_hip_event_create(&a->ev) != ZXC_OK) a->ev = NULL;
+    if (!a->h_st) return ZXC_ERROR_MEMORY;
+    if (!a->ev) return ZXC_ERROR_GPU_UNAVAILABLE;
+    int rc;
+    if (e->enqueue) {
+        rc = e->enqueue(e, s, stream);
+        if (dbg) dbg->up1 = pipe_now_ms();
+    } else {
+        const size_t need_comp = (s->p.comp_bytes > e->cap_comp ? s->p.comp_bytes : e->cap_comp) + 64; /* (+64: 16-byte reads past the last block) */
+        const size_t need_out = (s->p.out_bytes > e->cap_out ? s->p.out_bytes : e->cap_out) + 64;
+        b->d_comp = arena_reserve(a, AR_COMP, need_comp);
+        b->d_jobs = arena_reserve(a, AR_JOBS, (size_t)e->max_blocks * sizeof(zxc_dev_job_t));
+        b->d_out = arena_reserve(a, AR_OUT, need_out);
+        b->d_status = arena_reserve(a, AR_STATUS, (size_t)e->max_blocks * sizeof(int32_t));
+        if (!b->d_comp || !b->d_jobs || !b->d_out || !b->d_status) return ZXC_ERROR_MEMORY;
+        rc = zxc_hip_memcpy_h2d_async(b->d_comp, s->p.h_comp, s->p.comp_bytes, stream);
+        if (rc == ZXC_OK) rc = zxc_hip_memcpy_h2d_async(b->d_jobs, s->p.jobs, (size_t)n * sizeof(zxc_dev_job_t), stream);
+        const dict_ref_t* dr = e->dr;
+        if (rc == ZXC_OK && dr && dr->dict_size) {
+            b->d_dict = arena_reserve(a, AR_DICT, dr->dict_size + ZXC_HUF_TABLE_SIZE + 64);
+            if (!b->d_dict) rc = ZXC_ERROR_MEMORY;
+            if (rc == ZXC_OK && !s->dict_up) { /* once per slot and call (plain copies: they return when the bytes are there) */
+                rc = zxc_mi355x_memcpy_h2d(b->d_dict, dr->dict, dr->dict_size);
+                if (rc == ZXC_OK && dr->dict_huf) rc = zxc_mi355x_memcpy_h2d((uint8_t*)b->d_dict + dr->dict_size, dr->dict_huf, ZXC_HUF_TABLE_SIZE);
+                s->dict_up = rc == ZXC_OK;
+            }
+        }
+        if (dbg) dbg->up1 = pipe_now_ms();
+        if (rc == ZXC_OK)
+            rc = zxc_hip_decode_blocks(b->d_comp, (const zxc_dev_job_t*)b->d_jobs, n, b->d_out, (int32_t*)b->d_status, e->block_size, e->verify,
+                                       b->d_dict, b->d_dict ? (uint32_t)dr->dict_size : 0u,
+                                       (b->d_dict && dr->dict_huf) ? (uint8_t*)b->d_dict + dr->dict_size : NULL, 0u, stream);
+    }
+    if (rc == ZXC_OK) rc = zxc_hip_memcpy_d2h_async(a->h_st, b->d_status, (size_t)n * sizeof(int32_t), stream);
+    if (rc == ZXC_OK) rc = zxc_hip_event_record(a->ev, stream);
+    if (dbg) dbg->launched = pipe_now_ms();
+    return rc;
+}
+
+/* A producer: takes the next piece from the source when its slot is free (one producer at a time, in order), then uploads and
+ * enqueues it on its own stream while the other producer is already asking the source for the piece behind it. */
+static void* pipe_producer_main(void* arg) {
+    pipe_t* e = (pipe_t*)arg;
+    if (zxc_mi355x_set_device(e->device) != ZXC_OK) {
+        pthread_mutex_lock(&e->mu);
+        e->src_done = 1; /* (the consumer then finds no piece; pipe_run reports the failure through the first slot) */
+        e->slot[0].rc = ZXC_ERROR_GPU_UNAVAILABLE;
+        pthread_cond_broadcast(&e->cv);
+        pthread_mutex_unlock(&e->mu);
+        return NULL;
+    }
+    for (;;) {
+        pthread_mutex_lock(&e->src_mu);
+        pthread_mutex_lock(&e->mu);
+        while (!e->stop && !e->src_done && e->next - e->consumed >= (uint64_t)e->k) pthread_cond_wait(&e->cv, &e->mu);
+        const int quit = e->stop || e->src_done;
+        const uint64_t i = e->next;
+        pthread_mutex_unlock(&e->mu);
+        if (quit) { pthread_mutex_unlock(&e->src_mu); break; }
+        pipe_slot_t* s = &e->slot[i % (uint64_t)e->k];
+        if (g_pipe_dbg && i < PIPE_DBG_MAX) g_pipe_dbg[i].src0 = pipe_now_ms();
+        const int r = e->source(e->source_ctx, pipe_piece_blocks(e, i), &s->p);
+        pthread_mutex_lock(&e->mu);
+        if (r == 1) e->next = i + 1;
+        else {
+            e->src_done = 1;
+            if (r < 0) { s->rc = r; s->ready = i + 1; e->next = i + 1; } /* an error the consumer meets in its turn: behind every piece in front of it */
+            pthread_cond_broadcast(&e->cv);
+        }
+        pthread_mutex_unlock(&e->mu);
+        pthread_mutex_unlock(&e->src_mu);
+        if (r != 1) break;
+        const int rc = pipe_enqueue(e, i);
+        pthread_mutex_lock(&e->mu);
+        s->rc = rc;
+        s->ready = i + 1;
+        if (rc != ZXC_OK) e->src_done = 1;
+        pthread_cond_broadcast(&e->cv);
+        pthread_mutex_unlock(&e->mu);
+        if (rc != ZXC_OK) break;
     }
     return NULL;
+}
+
+/* Runs the pipeline until the source is exhausted (0), a sink stops it (its non-zero verdict) or something fails (< 0).
+ * total_comp / total_out: what the whole call can need at most (sizes the slots' reservations); piece_bytes: output per piece
+ * after the ramp (0: PIPE_PIECE_BYTES); first_sub: the arena this caller may wait for; want_slots: how many to try to hold. */
+static int pipe_run_ex(pipe_source_fn source, void* source_ctx, pipe_sink_fn sink, void* sink_ctx, pipe_enqueue_fn enqueue, void* enqueue_ctx,
+                       uint32_t block_size, int verify, const dict_ref_t* dr, size_t total_comp, uint64_t total_out, size_t piece_bytes,
+                       size_t first_bytes, int first_sub, int want_slots) {
+    if (zxc_mi355x_device_count() <= 0) return ZXC_ERROR_GPU_UNAVAILABLE;
+    const int dev = zxc_hip_current_device();
+    if (dev < 0 || dev >= HOST_MAX_DEVICES) return ZXC_ERROR_GPU_UNAVAILABLE;
+    pthread_once(&g_arena_once, arena_init_all);
+    pipe_t* e = (pipe_t*)calloc(1, sizeof *e);
+    if (!e) return ZXC_ERROR_MEMORY;
+    e->source = source;
+    e->source_ctx = source_ctx;
+    e->enqueue = enqueue;
+    e->enqueue_ctx = enqueue_ctx;
+    e->block_size = block_size;
+    e->verify = verify;
+    e->dr = dr;
+    e->device = dev;
+    int fixed = 0; /* (the test switch: every piece this size, no ramp) */
+    { const char* ev = getenv("ZXC_MI355X_FRAME_BATCH_MIB"); if (ev && atoi(ev) >= 1 && atoi(ev) <= 1024) { piece_bytes = (size_t)atoi(ev) << 20; fixed = 1; } }
+    if (piece_bytes == 0) piece_bytes = PIPE_PIECE_BYTES;
+    e->max_blocks = (uint32_t)(piece_bytes / block_size);
+    if (e->max_blocks < 16u) e->max_blocks = 16u;
+    e->first_blocks = fixed ? e->max_blocks : (uint32_t)((first_bytes ? first_bytes : PIPE_FIRST_BYTES) / block_size);
+    if (e->first_blocks < 16u) e->first_blocks = 16u;
+    if (e->first_blocks > e->max_blocks) e->first_blocks = e->max_blocks;
+    { /* a slot's reservation: the largest piece, or the whole call when that is smaller */
+        const uint64_t piece_out = (uint64_t)e->max_blocks * block_size, piece_comp = (uint64_t)e->max_blocks * ((uint64_t)block_size + 16u);
+        e->cap_out = (size_t)(total_out + block_size < piece_out ? total_out + block_size : piece_out);
+        e->cap_comp = (size_t)((uint64_t)total_comp < piece_comp ? (uint64_t)total_comp : piece_comp);
+        const uint64_t all_blocks = total_out / block_size + 1u;
+        e->cap_blocks = all_blocks < e->max_blocks ? (uint32_t)all_blocks : e->max_blocks;
+    }
+    const int one_piece = total_out <= (uint64_t)e->first_blocks * block_size;
+    if (one_piece || want_slots < 1) want_slots = 1;
+    if (want_slots > PIPE_SLOTS) want_slots = PIPE_SLOTS;
+    /* arenas: any free one first, else wait for `first_sub`; the others only if nobody holds them */
+    int held[ARENA_SUBS];
+    memset(held, 0, sizeof held);
+    for (int t = 0; t < ARENA_SUBS && e->k == 0; t++) {
+        const int sub = (first_sub + t) % ARENA_SUBS;
+        if (pthread_mutex_trylock(&g_arena[dev][sub].mu) == 0) { e->slot[e->k++].a = &g_arena[dev][sub]; held[sub] = 1; }
+    }
+    if (e->k == 0) { pthread_mutex_lock(&g_arena[dev][first_sub % ARENA_SUBS].mu); e->slot[e->k++].a = &g_arena[dev][first_sub % ARENA_SUBS]; held[first_sub % ARENA_SUBS] = 1; }
+    for (int sub = 0; sub < ARENA_SUBS && e->k < want_slots; sub++)
+        if (!held[sub] && pthread_mutex_trylock(&g_arena[dev][sub].mu) == 0) { e->slot[e->k++].a = &g_arena[dev][sub]; held[sub] = 1; }
+    int ret = 0;
+    for (int k = 0; k < e->k; k++) {
+        e->slot[k].p.jobs = (zxc_dev_job_t*)malloc((size_t)e->max_blocks * sizeof(zxc_dev_job_t));
+        if (!e->slot[k].p.jobs) ret = ZXC_ERROR_MEMORY;
+    }
+    const double t_begin = pipe_now_ms();
+    if (getenv("ZXC_MI355X_DEBUG_TIMES") && !g_pipe_dbg) g_pipe_dbg = (pipe_dbg_t*)calloc(PIPE_DBG_MAX, sizeof(pipe_dbg_t));
+    if (g_pipe_dbg) memset(g_pipe_dbg, 0, PIPE_DBG_MAX * sizeof(pipe_dbg_t));
+    /* producers: two with three or four slots (one piece in the sink, one or two being made), one with two slots */
+    pthread_t th[PIPE_PRODUCERS];
+    int started = 0;
+    for (int k = 0; k < e->k && ret == 0; k++) /* (a stream that cannot be created: that slot's pieces run on the default stream) */
+        if (!e->slot[k].a->stream && zxc_hip_stream_create(&e->slot[k].a->stream) != ZXC_OK) e->slot[k].a->stream = NULL;
+    if (ret == 0 && e->k >= 2) {
+        e->producers = e->k >= 3 ? PIPE_PRODUCERS : 1;
+        pthread_mutex_init(&e->mu, NULL);
+        pthread_mutex_init(&e->src_mu, NULL);
+        pthread_cond_init(&e->cv, NULL);
+        for (int q = 0; q < e->producers; q++) {
+            if (pthread_create(&th[started], NULL, pipe_producer_main, e) == 0) started++;
+            else break;
+        }
+        if (started == 0) { pthread_mutex_destroy(&e->mu); pthread_mutex_destroy(&e->src_mu); pthread_cond_destroy(&e->cv); }
+    }
+    if (ret == 0 && started) {
+        for (uint64_t i = 0; ret == 0; i++) {
+            pipe_slot_t* s = &e->slot[i % (uint64_t)e->k];
+            pthread_mutex_lock(&e->mu);
+            while (s->ready != i + 1 && !(e->src_done && i >= e->next)) pthread_cond_wait(&e->cv, &e->mu);
+            const int have = s->ready == i + 1;
+            pthread_mutex_unlock(&e->mu);
+            if (!have) { if (i == 0 && e->slot[0].rc < 0) ret = e->slot[0].rc; break; }
+            if (s->rc < 0) { ret = s->rc; break; }
+            ret = zxc_hip_event_synchronize(s->a->ev);
+            if (g_pipe_dbg && i < PIPE_DBG_MAX) g_pipe_dbg[i].ready = pipe_now_ms();
+            if (ret == 0) ret = sink(sink_ctx, &s->p, s->a->h_st, &s->b);
+            if (g_pipe_dbg && i < PIPE_DBG_MAX) g_pipe_dbg[i].sunk = pipe_now_ms();
+            pthread_mutex_lock(&e->mu);
+            e->consumed = i + 1;
+            pthread_cond_broadcast(&e->cv);
+            pthread_mutex_unlock(&e->mu);
+        }
+        pthread_mutex_lock(&e->mu);
+        e->stop = 1;
+        pthread_cond_broadcast(&e->cv);
+        pthread_mutex_unlock(&e->mu);
+        for (int q = 0; q < started; q++) pthread_join(th[q], NULL);
+        pthread_mutex_destroy(&e->mu);
+        pthread_mutex_destroy(&e->src_mu);
+        pthread_cond_destroy(&e->cv);
+    } else if (ret == 0) { /* one slot, in series on this thread */
+        e->k = 1; /* (the arenas beyond the first are released below all the same) */
+        for (uint64_t i = 0; ret == 0; i++) {
+            if (g_pipe_dbg && i < PIPE_DBG_MAX) g_pipe_dbg[i].src0 = pipe_now_ms();
+            const int r = e->source(e->source_ctx, pipe_piece_blocks(e, i), &e->slot[0].p);
+            if (r <= 0) { ret = r; break; }
+            ret = pipe_enqueue(e, i);
+            if (ret == 0) ret = zxc_hip_event_synchronize(e->slot[0].a->ev);
+            if (g_pipe_dbg && i < PIPE_DBG_MAX) g_pipe_dbg[i].ready = pipe_now_ms();
+            if (ret == 0) ret = sink(sink_ctx, &e->slot[0].p, e->slot[0].a->h_st, &e->slot[0].b);
+            if (g_pipe_dbg && i < PIPE_DBG_MAX) g_pipe_dbg[i].sunk = pipe_now_ms();
+        }
+    }
+    /* nothing of this call may still run on the arenas when they go back */
+    for (int sub = 0; sub < ARENA_SUBS; sub++)
+        if (held[sub]) (void)zxc_mi355x_synchronize(g_arena[dev][sub].stream);
+    if (g_pipe_dbg) {
+        fprintf(stderr, "[pipe] %d slot(s), %d producer thread(s), pieces of %u..%u blocks; ms since the call began:\n", e->k, started, e->first_blocks, e->max_blocks);
+        for (int i = 0; i < PIPE_DBG_MAX && g_pipe_dbg[i].n; i++)
+            fprintf(stderr, "[pipe]  piece %2d: %5u blocks %6.1f MiB in %6.1f MiB out | source %.2f, upload %.2f-%.2f, launched %.2f | ready %.2f, sunk %.2f\n", i,
+                    g_pipe_dbg[i].n, g_pipe_dbg[i].comp / 1048576.0, g_pipe_dbg[i].out / 1048576.0, g_pipe_dbg[i].src0 - t_begin, g_pipe_dbg[i].up0 - t_begin,
+                    g_pipe_dbg[i].up1 - t_begin, g_pipe_dbg[i].launched - t_begin, g_pipe_dbg[i].ready - t_begin, g_pipe_dbg[i].sunk - t_begin);
+        fprintf(stderr, "[pipe]  done at %.2f ms\n", pipe_now_ms() - t_begin);
+    }
+    for (int sub = 0; sub < ARENA_SUBS; sub++)
+        if (held[sub]) {
+            arena_t* a = &g_arena[dev][sub];
+            for (int w = 0; w < AR_N; w++)
+                if (a->buf[w].cap > ARENA_KEEP_MAX) { zxc_mi355x_free(a->buf[w].p); a->buf[w].p = NULL; a->buf[w].cap = 0; }
+            pthread_mutex_unlock(&a->mu);
+        }
+    for (int k = 0; k < PIPE_SLOTS; k++) { free(e->slot[k].p.jobs); free(e->slot[k].p.stage); }
+    free(e);
+    return ret;
+}
+
+static int pipe_run(pipe_source_fn source, void* source_ctx, pipe_sink_fn sink, void* sink_ctx, uint32_t block_size, int verify,
+                    const dict_ref_t* dr, size_t total_comp, uint64_t total_out, size_t piece_bytes, int first_sub, int want_slots) {
+    return pipe_run_ex(source, source_ctx, sink, sink_ctx, NULL, NULL, block_size, verify, dr, total_comp, total_out, piece_bytes, 0, first_sub, want_slots);
+}
+
+/* ------------------------------------------------------------ zxc_decompress */
+/* The 8-byte block headers are walked on the host into job tables, one piece at a time: device memory is O(piece), not a
+ * function of the untrusted block count, and decoding stops at the first failing or overflowing block like the reference's
+ * sequential loop (zxc_dispatch.c:912-1001). A problem found at block k is only reported if blocks 0..k-1 all decode (first
+ * failure in stream order wins). */
+typedef struct {
+    const uint8_t* src;
+    size_t src_size, ip;
+    uint32_t block_size;
+    int file_ck, verify;
+    int tail_err;         /* error to report after all queued blocks succeed */
+    int saw_eof, done;
+    uint32_t global_hash; /* rotl1-xor fold of the stored per-block checksums (zxc_internal.h:1390-1393) */
+} frame_walk_t;
+static int frame_source(void* ctx, uint32_t max_blocks, pipe_piece_t* p) {
+    frame_walk_t* w = (frame_walk_t*)ctx;
+    zxc_dev_job_t* jobs = p->jobs;
+    uint32_t n = 0;
+    const size_t span0 = w->ip;
+    const uint32_t hash0 = w->global_hash;
+    while (!w->done && n < max_blocks) {
+        if (w->ip >= w->src_size) { w->done = 1; break; }
+        const size_t rem = w->src_size - w->ip;
+        uint8_t type;
+        uint32_t csz;
+        if (read_block_header(w->src + w->ip, rem, &type, &csz) != ZXC_OK) { w->tail_err = ZXC_ERROR_BAD_HEADER; w->done = 1; break; }
+        if (type == BLK_EOF) {
+            if (csz != 0) w->tail_err = ZXC_ERROR_BAD_HEADER;
+            w->saw_eof = 1;
+            w->done = 1;
+            break;
+        }
+        const uint64_t phys = (uint64_t)BLK_HDR + csz + (w->file_ck ? 4u : 0u);
+        jobs[n].comp_off = w->ip - span0;
+        /* the wrapper sees "all remaining bytes"; any size >= the physical block is equivalent */
+        { const uint64_t cs = phys < rem ? phys : rem; jobs[n].comp_size = cs > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cs; }
+        jobs[n].out_off = (uint64_t)n * w->block_size;
+        jobs[n].out_len = w->block_size;
+        n++;
+        if (w->verify && phys <= rem)
+            w->global_hash = ((w->global_hash << 1) | (w->global_hash >> 31)) ^ rd32(w->src + w->ip + BLK_HDR + csz);
+        if (phys >= rem) { w->ip = w->src_size; w->done = 1; break; }
+        w->ip += (size_t)phys;
+    }
+    if (n == 0) return 0;
+    p->h_comp = w->src + span0;
+    p->comp_bytes = w->ip - span0;
+    p->n = n;
+    p->out_bytes = (size_t)n * w->block_size;
+    /* the walk in front of and behind this piece: the caller restarts from either when a piece turns out irregular */
+    p->cookie[0] = span0;
+    p->cookie[1] = hash0;
+    p->cookie[2] = w->ip;
+    p->cookie[3] = w->global_hash;
+    p->cookie[4] = (uint64_t)w->done | ((uint64_t)w->saw_eof << 1);
+    p->cookie[5] = (uint64_t)(uint32_t)w->tail_err;
+    return 1;
+}
+typedef struct {
+    uint8_t* dst;
+    size_t dst_capacity, total;
+    uint32_t block_size;
+    uint64_t irr[6]; /* cookie of the piece that turned out irregular */
+} frame_sink_t;
+static int frame_sink(void* ctx, const pipe_piece_t* p, const int32_t* st, const dev_bufs_t* b) {
+    frame_sink_t* k = (frame_sink_t*)ctx;
+    /* sequential semantics: first failing block wins; sizes accumulate in order. A block that is not the frame's last and
+     * decodes to another size than block_size makes the frame irregular (legal, never produced by the reference encoder):
+     * blocks no longer sit back to back in the slot layout. */
+    const int last_piece = (int)(p->cookie[4] & 1u);
+    int regular = 1;
+    size_t piece_total = 0;
+    for (uint32_t i = 0; i < p->n; i++) {
+        if (st[i] < 0) return st[i];
+        if ((size_t)st[i] > k->dst_capacity - k->total - piece_total) return ZXC_ERROR_DST_TOO_SMALL;
+        if ((uint32_t)st[i] != k->block_size && !(last_piece && i + 1 == p->n)) regular = 0;
+        if ((uint32_t)st[i] > k->block_size) regular = 0;
+        piece_total += (size_t)st[i];
+    }
+    if (!regular) { memcpy(k->irr, p->cookie, sizeof k->irr); return PIPE_IRREGULAR; }
+    const int rc = zxc_mi355x_memcpy_d2h(k->dst + k->total, b->d_out, piece_total);
+    if (rc != ZXC_OK) return rc;
+    k->total += piece_total;
+    return 0;
+}
+/* An irregular piece: decoded sizes are a property of the blocks alone — run it again with one cap-sized slot per block and
+ * gather block by block (in series: this path exists for correctness, the reference encoder never writes such frames). */
+static int frame_irregular_piece(frame_walk_t* w, frame_sink_t* k, const dict_ref_t* dr, uint32_t max_blocks) {
+    const uint32_t slot = (w->block_size + TAIL_PAD + 15u) & ~15u;
+    pipe_piece_t p;
+    memset(&p, 0, sizeof p);
+    p.jobs = (zxc_dev_job_t*)malloc((size_t)max_blocks * sizeof(zxc_dev_job_t));
+    int32_t* st = (int32_t*)malloc((size_t)max_blocks * sizeof(int32_t));
+    int rc = (p.jobs && st) ? ZXC_OK : ZXC_ERROR_MEMORY;
+    if (rc == ZXC_OK && frame_source(w, max_blocks, &p) != 1) rc = ZXC_ERROR_CORRUPT_DATA; /* (cannot happen: the walk was rewound to a piece) */
+    dev_bufs_t b;
+    memset(&b, 0, sizeof b);
+    if (rc == ZXC_OK) {
+        for (uint32_t i = 0; i < p.n; i++) { p.jobs[i].out_off = (uint64_t)i * slot; p.jobs[i].out_len = slot; }
+        rc = run_jobs_on(p.h_comp, p.comp_bytes, p.jobs, p.n, (size_t)p.n * slot, w->block_size, 0u, w->verify, st, &b, dr, 0, NULL);
+        if (rc != ZXC_OK) memset(&b, 0, sizeof b);
+    }
+    for (uint32_t i = 0; i < p.n && rc == ZXC_OK; i++) {
+        /* a status is never trusted as a copy length */
+        if (st[i] < 0) { rc = st[i]; break; }
+        if ((size_t)st[i] > k->dst_capacity - k->total) { rc = ZXC_ERROR_DST_TOO_SMALL; break; }
+        if ((uint32_t)st[i] > slot) { rc = ZXC_ERROR_CORRUPT_DATA; break; }
+        rc = zxc_mi355x_memcpy_d2h(k->dst + k->total, (const uint8_t*)b.d_out + (size_t)i * slot, (size_t)st[i]);
+        k->total += (size_t)st[i];
+    }
+    dev_bufs_free(&b);
+    free(p.jobs);
+    free(st);
+    return rc;
 }
 
 int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, const size_t dst_capacity,
@@ -497,174 +911,50 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
     if (dict_size > ZXC_DICT_SIZE_MAX) return ZXC_ERROR_DICT_TOO_LARGE;
     const dict_ref_t dr = {dict, dict_size, dict_huf};
 
-    /* The 8-byte block headers are walked on the host into a job table, one bounded batch at a time
-     * (at most HOST_BATCH_BYTES of output slots per launch): device memory is O(batch), not a function
-     * of the untrusted block count, and decoding stops at the first failing or overflowing block like
-     * the reference's sequential loop (zxc_dispatch.c:912-1001). A problem found at block k is only
-     * reported if blocks 0..k-1 all decode (first failure in stream order wins). */
-    size_t batch_bytes = FRAME_BATCH_BYTES;
-    { const char* e = getenv("ZXC_MI355X_FRAME_BATCH_MIB"); if (e && atoi(e) >= 1 && atoi(e) <= 1024) batch_bytes = (size_t)atoi(e) << 20; }
-    uint32_t batch_blocks = (uint32_t)(batch_bytes / block_size);
-    if (batch_blocks < 16u) batch_blocks = 16u;
-    /* Two batches in flight: while batch i's decoded bytes go back to the host on this thread, a helper thread uploads batch
-     * i+1 (its own arena, its own stream) — the link carries both directions at once. W[k]: the walked batch in slot k. */
-    struct { zxc_dev_job_t* jobs; int32_t* st; uint32_t n; size_t span0, span; int last, uploaded; dev_bufs_t b; } W[2];
-    memset(W, 0, sizeof W);
-    for (int k = 0; k < 2; k++) {
-        W[k].jobs = (zxc_dev_job_t*)malloc((size_t)batch_blocks * sizeof(zxc_dev_job_t));
-        W[k].st = (int32_t*)malloc((size_t)batch_blocks * sizeof(int32_t));
+    frame_walk_t w;
+    memset(&w, 0, sizeof w);
+    w.src = src;
+    w.src_size = src_size;
+    w.ip = ZXC_FILE_HEADER_SIZE;
+    w.block_size = block_size;
+    w.file_ck = file_ck;
+    w.verify = verify;
+    frame_sink_t k;
+    memset(&k, 0, sizeof k);
+    k.dst = dst;
+    k.dst_capacity = dst_capacity;
+    k.block_size = block_size;
+    /* (the footer's size is a hint for the slots' reservations only: bounded by the caller's capacity) */
+    uint64_t out_hint = rd64(src + src_size - ZXC_FILE_FOOTER_SIZE);
+    if (out_hint > (uint64_t)dst_capacity) out_hint = dst_capacity;
+    for (;;) {
+        const int r = pipe_run(frame_source, &w, frame_sink, &k, block_size, verify, &dr, src_size, out_hint, 0, 0, PIPE_DECODE_SLOTS);
+        if (r < 0) return r;
+        if (r != PIPE_IRREGULAR) break;
+        /* rewind the walk (it ran ahead of the sink) to the front of the irregular piece, take that piece block by block ... */
+        w.ip = (size_t)k.irr[0];
+        w.global_hash = (uint32_t)k.irr[1];
+        w.done = 0;
+        w.saw_eof = 0;
+        w.tail_err = 0;
+        uint32_t nb = (uint32_t)(PIPE_PIECE_BYTES / block_size); /* (at most what a piece can hold: the walk stops where the piece did) */
+        { const char* ev = getenv("ZXC_MI355X_FRAME_BATCH_MIB"); if (ev && atoi(ev) >= 1 && atoi(ev) <= 1024) nb = (uint32_t)(((size_t)atoi(ev) << 20) / block_size); }
+        if (nb < 16u) nb = 16u;
+        /* the piece had exactly this many blocks or fewer: walk block by block up to where it ended */
+        while (w.ip < (size_t)k.irr[2] && !w.done) {
+            const int rc = frame_irregular_piece(&w, &k, &dr, nb);
+            if (rc != ZXC_OK) return rc;
+        }
+        /* ... and go on behind it */
+        if (w.done) break;
     }
-    if (!W[0].jobs || !W[1].jobs || !W[0].st || !W[1].st) {
-        for (int k = 0; k < 2; k++) { free(W[k].jobs); free(W[k].st); }
-        return ZXC_ERROR_MEMORY;
-    }
-    size_t ip = ZXC_FILE_HEADER_SIZE;
-    int tail_err = 0;         /* error to report after all queued blocks succeed */
-    uint32_t global_hash = 0; /* rotl1-xor fold of the stored per-block checksums (zxc_internal.h:1390-1393) */
-    int saw_eof = 0, done = 0;
-    int64_t ret = 0;
-    size_t total = 0;
-    const uint32_t slot = (block_size + TAIL_PAD + 15u) & ~15u;
-    void* up_stream = NULL;   /* the helper's stream, created with the first second batch */
-    /* the 8-byte block headers of the next batch -> W[k] (host only) */
-#define WALK_BATCH(k)                                                                                                      \
-    do {                                                                                                                   \
-        zxc_dev_job_t* jobs = W[k].jobs;                                                                                   \
-        uint32_t n = 0;                                                                                                    \
-        const size_t span0 = ip;                                                                                           \
-        while (!done && n < batch_blocks) {                                                                                \
-            if (ip >= src_size) { done = 1; break; }                                                                       \
-            const size_t rem = src_size - ip;                                                                              \
-            uint8_t type;                                                                                                  \
-            uint32_t csz;                                                                                                  \
-            if (read_block_header(src + ip, rem, &type, &csz) != ZXC_OK) { tail_err = ZXC_ERROR_BAD_HEADER; done = 1; break; } \
-            if (type == BLK_EOF) {                                                                                         \
-                if (csz != 0) tail_err = ZXC_ERROR_BAD_HEADER;                                                             \
-                saw_eof = 1;                                                                                               \
-                done = 1;                                                                                                  \
-                break;                                                                                                     \
-            }                                                                                                              \
-            const uint64_t phys = (uint64_t)BLK_HDR + csz + (file_ck ? 4u : 0u);                                           \
-            jobs[n].comp_off = ip - span0;                                                                                 \
-            /* the wrapper sees "all remaining bytes"; any size >= the physical block is equivalent */                    \
-            { const uint64_t cs = phys < rem ? phys : rem; jobs[n].comp_size = cs > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cs; } \
-            jobs[n].out_off = (uint64_t)n * block_size;                                                                    \
-            jobs[n].out_len = block_size;                                                                                  \
-            n++;                                                                                                           \
-            if (verify && phys <= rem)                                                                                     \
-                global_hash = ((global_hash << 1) | (global_hash >> 31)) ^ rd32(src + ip + BLK_HDR + csz);                 \
-            if (phys >= rem) { ip = src_size; done = 1; break; }                                                           \
-            ip += (size_t)phys;                                                                                            \
-        }                                                                                                                  \
-        W[k].n = n;                                                                                                        \
-        W[k].span0 = span0;                                                                                                \
-        W[k].span = ip - span0;                                                                                            \
-        W[k].last = done;                                                                                                  \
-    } while (0)
-    int cur = 0;
-    WALK_BATCH(0);
-    const int my_dev = zxc_hip_current_device();
-    while (W[cur].n && ret == 0) {
-        const uint32_t n = W[cur].n;
-        zxc_dev_job_t* jobs = W[cur].jobs;
-        const size_t span0 = W[cur].span0, span = W[cur].span;
-        int32_t* st = W[cur].st;
-        int rc = ZXC_OK;
-        dev_bufs_t b;
-        if (!W[cur].uploaded) { /* the first batch, or one whose arena was busy when it was walked: this thread holds nothing here */
-            rc = jobs_upload(src + span0, span, jobs, n, (size_t)n * block_size, &W[cur].b, &dr, cur, NULL, NULL);
-            b = W[cur].b;
-            W[cur].n = 0; /* (from here on `b` owns the arena) */
-            if (rc == ZXC_OK) rc = jobs_execute(&b, n, block_size, 0u, verify, st, &dr, NULL);
-        } else { /* uploaded AND decoded by the helper, statuses in st */
-            b = W[cur].b;
-            W[cur].n = 0;
-        }
-        if (rc != ZXC_OK) { ret = rc; break; }
-        /* the next batch: walked here, uploaded AND decoded by the helper (its own arena and stream) while this batch's output is
-         * copied back: three stages overlap — a launch costs ~0.5 ms whatever its size, serial per batch that was 0.6 ms of every
-         * batch (profiles/r4c_host_api.log) */
-        const int nxt = cur ^ 1;
-        host_upload_t up;
-        memset(&up, 0, sizeof up);
-        pthread_t up_thread;
-        int up_live = 0;
-        W[nxt].n = 0;
-        W[nxt].uploaded = 0;
-        if (!done) {
-            WALK_BATCH(nxt);
-            /* the other arena, if nobody holds it (never WAIT for a second arena while holding one: two such callers would
-             * wait for each other); else the batch is uploaded in series when this one is done */
-            arena_t* na = (W[nxt].n && my_dev >= 0 && my_dev < HOST_MAX_DEVICES) ? &g_arena[my_dev][nxt] : NULL;
-            if (na && !up_stream && zxc_hip_stream_create(&up_stream) != ZXC_OK) up_stream = NULL;
-            if (na && up_stream && pthread_mutex_trylock(&na->mu) == 0) {
-                up = (host_upload_t){src + W[nxt].span0, W[nxt].span, W[nxt].jobs, W[nxt].n, (size_t)W[nxt].n * block_size, &W[nxt].b, &dr,
-                                     nxt, up_stream, na, my_dev, ZXC_OK, block_size, verify, W[nxt].st};
-                up_live = pthread_create(&up_thread, NULL, host_upload_main, &up) == 0;
-                if (!up_live) host_upload_main(&up); /* (no thread: upload it here, in series) */
-                W[nxt].uploaded = 1;
-            }
-        }
-        /* sequential semantics: first failing block wins; sizes accumulate in order. A block that is not the
-         * frame's last and decodes to another size than block_size makes the frame irregular (legal, never
-         * produced by the reference encoder): blocks no longer sit back to back in the slot layout. */
-        int regular = 1;
-        size_t batch_total = 0;
-        for (uint32_t i = 0; i < n; i++) {
-            if (st[i] < 0) { ret = st[i]; break; }
-            if ((size_t)st[i] > dst_capacity - total - batch_total) { ret = ZXC_ERROR_DST_TOO_SMALL; break; }
-            if ((uint32_t)st[i] != block_size && !(W[cur].last && i + 1 == n)) regular = 0;
-            if ((uint32_t)st[i] > block_size) regular = 0;
-            batch_total += (size_t)st[i];
-        }
-        if (ret == 0 && regular) {
-            const int crc = zxc_mi355x_memcpy_d2h(dst + total, b.d_out, batch_total);
-            if (crc != ZXC_OK) ret = crc;
-        }
-        if (up_live) pthread_join(up_thread, NULL);
-        if (W[nxt].uploaded && up.rc != ZXC_OK) { /* a failed upload: its arena is ours to release */
-            if (ret == 0) ret = up.rc;
-            W[nxt].b.held = up.arena;
-            dev_bufs_free(&W[nxt].b);
-            W[nxt].n = 0;
-            W[nxt].uploaded = 0;
-        }
-        if (ret == 0 && !regular) {
-            /* decoded sizes are a property of the blocks alone: re-run this batch with one cap-sized slot
-             * per block and gather. (The prefetched batch gives its arena back first — this thread is about to wait for one —
-             * and goes up again, in series, when its turn comes.) */
-            if (W[nxt].uploaded) { dev_bufs_free(&W[nxt].b); W[nxt].uploaded = 0; }
-            dev_bufs_free(&b);
-            for (uint32_t i = 0; i < n; i++) { jobs[i].out_off = (uint64_t)i * slot; jobs[i].out_len = slot; }
-            rc = run_jobs_on(src + span0, span, jobs, n, (size_t)n * slot, block_size, 0u, verify, st, &b, &dr, cur, NULL);
-            if (rc != ZXC_OK) { ret = rc; memset(&b, 0, sizeof b); }
-            size_t op = total;
-            for (uint32_t i = 0; i < n && rc == ZXC_OK; i++) {
-                /* the second run must reproduce the first one's verdicts: a status is never trusted as a copy length */
-                if (st[i] < 0) { rc = st[i]; break; }
-                if ((uint32_t)st[i] > slot || (size_t)st[i] > dst_capacity - op) { rc = ZXC_ERROR_CORRUPT_DATA; break; }
-                rc = zxc_mi355x_memcpy_d2h(dst + op, (const uint8_t*)b.d_out + (size_t)i * slot, (size_t)st[i]);
-                op += (size_t)st[i];
-            }
-            if (rc != ZXC_OK && ret == 0) ret = rc;
-        }
-        dev_bufs_free(&b);
-        total += batch_total;
-        cur = nxt;
-    }
-#undef WALK_BATCH
-    for (int k = 0; k < 2; k++)
-        if (W[k].n && W[k].uploaded) dev_bufs_free(&W[k].b); /* (an uploaded batch that is not going to run: give its arena back) */
-    zxc_hip_stream_destroy(up_stream);
-    for (int k = 0; k < 2; k++) { free(W[k].jobs); free(W[k].st); }
-    if (ret < 0) return ret;
-    if (tail_err) return tail_err;
-    if (saw_eof) { /* footer: stored size must equal what was produced (zxc_dispatch.c:936-943) */
+    if (w.tail_err) return w.tail_err;
+    if (w.saw_eof) { /* footer: stored size must equal what was produced (zxc_dispatch.c:936-943) */
         const uint8_t* footer = src + src_size - ZXC_FILE_FOOTER_SIZE;
-        if (rd64(footer) != (uint64_t)total) return ZXC_ERROR_CORRUPT_DATA;
-        if (verify && rd32(footer + 8) != global_hash) return ZXC_ERROR_BAD_CHECKSUM; /* :945-952 */
+        if (rd64(footer) != (uint64_t)k.total) return ZXC_ERROR_CORRUPT_DATA;
+        if (verify && rd32(footer + 8) != w.global_hash) return ZXC_ERROR_BAD_CHECKSUM; /* :945-952 */
     }
-    return (int64_t)total;
+    return (int64_t)k.total;
 }
 
 /* ------------------------------------------------ in-place decode (one buffer) */
@@ -718,137 +1008,114 @@ static void wr64(uint8_t* p, uint64_t v) {
     wr32(p + 4, (uint32_t)(v >> 32));
 }
 
-/* zxc_compress over batches of blocks (round 4): a helper thread uploads batch i + 1 and launches its encode on that slot's
- * stream while this thread turns batch i's block sizes into offsets, compacts the slots (zxc_gather_blocks_kernel) and brings
- * the bytes back — H2D, kernel and D2H of neighbouring batches overlap. One-shot this was 1 GiB in 56 ms = H2D + 29 ms of
- * kernel + D2H in series; batched 44 ms, now bound by the encode launches themselves (2 048 blocks = one workgroup per slot of
- * the chip, under the copies' traffic); a second upload thread and 96-384 MiB batches measured the same
- * (profiles/r4c_host_api.log; ZXC_MI355X_DEBUG_TIMES=1 prints the phases). */
-typedef struct {
-    void *d_src, *d_slots, *d_sizes, *d_offs, *d_out, *stream;
-} comp_slot_t;
+/* zxc_compress over pieces of blocks, through the piece pipeline above (round 5): two producer threads upload the source pieces
+ * and launch their encodes (a piece's encode takes ~3.5 ms whatever its size — one round of wavefronts — so three pieces sit in
+ * flight and fill the chip), the calling thread turns a finished piece's block sizes into offsets, compacts its slots
+ * (zxc_gather_blocks_kernel) and brings the bytes back; device buffers live in the staging arenas across calls. Round 4: one helper
+ * thread, upload and launch of batch i + 1 in series beside the download of batch i, 3 ms of hipMalloc / hipFree per call:
+ * 1 GiB in 41-44 ms against 28 ms of encode launches. Archives are byte for byte the one-shot ones whatever the piece size
+ * (tests/test_gpu_encode.py); ZXC_MI355X_DEBUG_TIMES=1 prints the pieces' timeline. */
 typedef struct {
     const uint8_t* src;
-    size_t bytes;
-    uint32_t block_size;
-    int level, checksum, device, rc;
-    comp_slot_t* s;
-} comp_up_t;
-static void* comp_up_main(void* arg) {
-    comp_up_t* u = (comp_up_t*)arg;
-    u->rc = zxc_mi355x_set_device(u->device);
-    if (u->rc == ZXC_OK) u->rc = zxc_hip_memcpy_h2d_async(u->s->d_src, u->src, u->bytes, u->s->stream);
-    if (u->rc == ZXC_OK)
-        u->rc = zxc_mi355x_encode_blocks_device(u->s->d_src, u->bytes, u->block_size, u->level, u->checksum, u->s->d_slots,
-                                                (uint32_t*)u->s->d_sizes, u->s->stream);
-    return NULL;
+    size_t src_size, block_size;
+    uint32_t next, nb;
+} comp_src_t;
+static int comp_source(void* ctx, uint32_t max_blocks, pipe_piece_t* p) {
+    comp_src_t* c = (comp_src_t*)ctx;
+    if (c->next >= c->nb) return 0;
+    const uint32_t f = c->next, n = c->nb - f < max_blocks ? c->nb - f : max_blocks;
+    const size_t o = (size_t)f * c->block_size;
+    p->h_comp = c->src + o; /* (here: the SOURCE bytes of the piece's blocks) */
+    p->comp_bytes = c->src_size - o < (size_t)n * c->block_size ? c->src_size - o : (size_t)n * c->block_size;
+    p->n = n;
+    p->out_bytes = (size_t)n * (c->block_size + 64);
+    p->cookie[0] = f;
+    c->next = f + n;
+    return 1;
 }
-static void comp_slot_free(comp_slot_t* s) {
-    zxc_mi355x_free(s->d_src);
-    zxc_mi355x_free(s->d_slots);
-    zxc_mi355x_free(s->d_sizes);
-    zxc_mi355x_free(s->d_offs);
-    zxc_mi355x_free(s->d_out);
-    zxc_hip_stream_destroy(s->stream);
-    memset(s, 0, sizeof *s);
+typedef struct { int level, checksum; } comp_enq_t;
+/* a slot's buffers in dev_bufs_t terms: d_comp = the source piece, d_dict = the encoder's per-block slots, d_status = block sizes,
+ * d_jobs = the blocks' offsets in the compacted output, d_out = that output */
+static int comp_enqueue(struct pipe_s* e, pipe_slot_t* s, void* stream) {
+    const comp_enq_t* c = (const comp_enq_t*)e->enqueue_ctx;
+    arena_t* a = s->a;
+    dev_bufs_t* b = &s->b;
+    const uint32_t stride = zxc_mi355x_encode_slot_stride(e->block_size);
+    b->d_comp = arena_reserve(a, AR_COMP, (size_t)e->cap_blocks * e->block_size + 64);
+    b->d_dict = arena_reserve(a, AR_SLOTS, (size_t)e->cap_blocks * stride);
+    b->d_status = arena_reserve(a, AR_STATUS, (size_t)e->max_blocks * sizeof(int32_t));
+    b->d_jobs = arena_reserve(a, AR_JOBS, (size_t)e->max_blocks * sizeof(zxc_dev_job_t));
+    b->d_out = arena_reserve(a, AR_OUT, (size_t)e->cap_blocks * ((size_t)e->block_size + 72) + 64); /* (a block is never larger than RAW: header + bytes + trailer) */
+    if (!b->d_comp || !b->d_dict || !b->d_status || !b->d_jobs || !b->d_out) return ZXC_ERROR_MEMORY;
+    int rc = zxc_hip_memcpy_h2d_async(b->d_comp, s->p.h_comp, s->p.comp_bytes, stream);
+    if (rc == ZXC_OK)
+        rc = zxc_mi355x_encode_blocks_device(b->d_comp, s->p.comp_bytes, e->block_size, c->level, c->checksum, b->d_dict, (uint32_t*)b->d_status, stream);
+    /* the compaction follows on the same stream, offsets computed on the device: behind three pieces' encodes a launch from the
+     * sink (round 4: sizes to the host, offsets back, gather on the default stream) waited milliseconds for a free compute unit */
+    if (rc == ZXC_OK) rc = zxc_hip_block_offsets((uint32_t*)b->d_status, (uint64_t*)b->d_jobs, s->p.n, e->block_size + 65u, stream);
+    if (rc == ZXC_OK)
+        rc = zxc_mi355x_gather_blocks_device(b->d_dict, e->block_size, (const uint32_t*)b->d_status, (const uint64_t*)b->d_jobs, b->d_out, s->p.n, stream);
+    return rc;
 }
-/* -> ZXC_OK and *op_io advanced over the nb encoded blocks, sizes[] and *hash_io filled; or a negative zxc_error_t */
-static int compress_batches(const uint8_t* src, size_t src_size, size_t block_size, int level, int checksum_enabled, size_t tail_need,
-                            uint8_t* dst, size_t dst_capacity, size_t* op_io, uint32_t* sizes, uint32_t nb, uint32_t batch_blocks,
-                            uint32_t* hash_io) {
-    const uint32_t stride = zxc_mi355x_encode_slot_stride((uint32_t)block_size);
-    const size_t batch_bytes = (size_t)batch_blocks * block_size;
-    const int device = zxc_hip_current_device();
-    const int dbg = getenv("ZXC_MI355X_DEBUG_TIMES") != NULL;
-    struct timespec t_[8];
-#define TS(k) do { if (dbg) clock_gettime(CLOCK_MONOTONIC, &t_[k]); } while (0)
-#define MS(a, b) ((t_[b].tv_sec - t_[a].tv_sec) * 1e3 + (t_[b].tv_nsec - t_[a].tv_nsec) / 1e6)
-    TS(0);
-    comp_slot_t S[2];
-    memset(S, 0, sizeof S);
-    uint64_t* offs = (uint64_t*)malloc((size_t)batch_blocks * sizeof(uint64_t));
-    int rc = offs ? ZXC_OK : ZXC_ERROR_MEMORY;
-    for (int k = 0; k < 2 && rc == ZXC_OK; k++) {
-        S[k].d_src = zxc_mi355x_malloc(batch_bytes + 64);
-        S[k].d_slots = zxc_mi355x_malloc((size_t)batch_blocks * stride);
-        S[k].d_sizes = zxc_mi355x_malloc((size_t)batch_blocks * 4);
-        S[k].d_offs = zxc_mi355x_malloc((size_t)batch_blocks * 8);
-        S[k].d_out = zxc_mi355x_malloc((size_t)batch_blocks * (block_size + 64) + 64); /* (a block is never larger than RAW: header + bytes + trailer) */
-        if (!S[k].d_src || !S[k].d_slots || !S[k].d_sizes || !S[k].d_offs || !S[k].d_out) rc = ZXC_ERROR_MEMORY;
-        if (rc == ZXC_OK) rc = zxc_hip_stream_create(&S[k].stream);
+typedef struct {
+    uint8_t* dst;
+    size_t dst_capacity, op, tail_need, block_size;
+    uint32_t* sizes; /* [nb]: the seek table's entries */
+    uint64_t* offs;  /* scratch, one piece */
+    uint32_t global_hash;
+    int checksum;
+} comp_sink_t;
+static int comp_sink(void* ctx, const pipe_piece_t* p, const int32_t* st, const dev_bufs_t* b) {
+    comp_sink_t* k = (comp_sink_t*)ctx;
+    const uint32_t f = (uint32_t)p->cookie[0], n = p->n;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t sz = (uint32_t)st[i];
+        /* (never trusted as a copy length, nor as the place of the trailer the global hash is folded from: a block is at least its
+         *  8-byte header, + 4 with checksums) */
+        if (sz > k->block_size + 64 || sz < 8u + (k->checksum ? 4u : 0u)) return ZXC_ERROR_CORRUPT_DATA;
+        k->sizes[f + i] = sz;
+        k->offs[i] = total;
+        total += sz;
     }
-    size_t op = *op_io;
-    uint32_t global_hash = *hash_io;
-    const uint32_t nbatches = (nb + batch_blocks - 1) / batch_blocks;
-    comp_up_t up;
-    memset(&up, 0, sizeof up);
-    TS(1);
-    if (dbg) fprintf(stderr, "[zxc_compress] device buffers + streams %.2f ms\n", MS(0, 1));
-    if (rc == ZXC_OK) { /* batch 0: uploaded and launched here */
-        up = (comp_up_t){src, src_size < batch_bytes ? src_size : batch_bytes, (uint32_t)block_size, level, checksum_enabled, device, ZXC_OK, &S[0]};
-        comp_up_main(&up);
-        rc = up.rc;
-    }
-    for (uint32_t bi = 0; bi < nbatches && rc == ZXC_OK; bi++) {
-        comp_slot_t* s = &S[bi & 1];
-        const uint32_t b0 = bi * batch_blocks, nbi = nb - b0 < batch_blocks ? nb - b0 : batch_blocks;
-        pthread_t th;
-        int live = 0, started = 0;
-        if (bi + 1 < nbatches) { /* the next batch, on the other slot (its last user, batch bi - 1, is done) */
-            const size_t o = (size_t)(bi + 1) * batch_bytes;
-            up = (comp_up_t){src + o, src_size - o < batch_bytes ? src_size - o : batch_bytes, (uint32_t)block_size, level, checksum_enabled, device, ZXC_OK, &S[(bi + 1) & 1]};
-            started = 1;
-            live = pthread_create(&th, NULL, comp_up_main, &up) == 0;
-            if (!live) comp_up_main(&up); /* (no thread: in series) */
-        }
-        TS(2);
-        rc = zxc_mi355x_synchronize(s->stream);
-        TS(3);
-        /* From here on this thread works on the default stream with synchronous calls: the runtime maps streams onto a few
-         * hardware queues, and when this slot's stream shares one with the other slot's, anything queued on it now would
-         * stand behind batch i + 1's upload and encode (measured inside a process that holds other streams: the 8 KiB of
-         * sizes took 4.7 ms, the call ran at one-shot speed). */
-        if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(sizes + b0, s->d_sizes, (size_t)nbi * 4);
-        uint64_t total = 0;
-        if (rc == ZXC_OK) {
-            for (uint32_t i = 0; i < nbi; i++) {
-                /* (never trusted as a copy length, nor as the place of the trailer the global hash is folded from: a block is at
-                 *  least its 8-byte header, + 4 with checksums) */
-                if (sizes[b0 + i] > block_size + 64 || sizes[b0 + i] < 8u + (checksum_enabled ? 4u : 0u)) { rc = ZXC_ERROR_CORRUPT_DATA; break; }
-                offs[i] = total;
-                total += sizes[b0 + i];
-            }
-            if (rc == ZXC_OK && (uint64_t)op + total + tail_need > (uint64_t)dst_capacity) rc = ZXC_ERROR_DST_TOO_SMALL;
-        }
-        TS(4);
-        if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_h2d(s->d_offs, offs, (size_t)nbi * 8);
-        if (rc == ZXC_OK)
-            rc = zxc_mi355x_gather_blocks_device(s->d_slots, (uint32_t)block_size, (const uint32_t*)s->d_sizes, (const uint64_t*)s->d_offs,
-                                                 s->d_out, nbi, NULL);
-        if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(dst + op, s->d_out, (size_t)total); /* (ordered behind the gather, returns when the bytes are here) */
-        if (rc == ZXC_OK && checksum_enabled) /* fold the block trailers in stream order (zxc_dispatch.c:754-759) */
-            for (uint32_t i = 0; i < nbi; i++)
-                global_hash = ((global_hash << 1) | (global_hash >> 31)) ^ rd32(dst + op + offs[i] + sizes[b0 + i] - 4);
-        if (rc == ZXC_OK) op += (size_t)total;
-        TS(5);
-        if (live) pthread_join(th, NULL);
-        TS(6);
-        if (dbg) fprintf(stderr, "[zxc_compress] batch %u: wait for its encode %.2f, sizes %.2f, offsets + gather + download %.2f, wait for the next upload %.2f ms\n", bi, MS(2, 3), MS(3, 4), MS(4, 5), MS(5, 6));
-        if (started && rc == ZXC_OK) rc = up.rc;
-    }
-    /* nothing of ours may still be running on the slots when they are freed */
-    for (int k = 0; k < 2; k++)
-        if (S[k].stream) (void)zxc_mi355x_synchronize(S[k].stream);
-    TS(6);
-    for (int k = 0; k < 2; k++) comp_slot_free(&S[k]);
-    free(offs);
-    TS(7);
-    if (dbg) fprintf(stderr, "[zxc_compress] release %.2f ms\n", MS(6, 7));
-#undef TS
-#undef MS
+    if ((uint64_t)k->op + total + k->tail_need > (uint64_t)k->dst_capacity) return ZXC_ERROR_DST_TOO_SMALL;
+    /* (the piece's blocks sit compacted in d_out: comp_enqueue) */
+    const int rc = zxc_mi355x_memcpy_d2h(k->dst + k->op, b->d_out, (size_t)total);
     if (rc != ZXC_OK) return rc;
-    *op_io = op;
-    *hash_io = global_hash;
+    if (k->checksum) /* fold the block trailers in stream order (zxc_dispatch.c:754-759) */
+        for (uint32_t i = 0; i < n; i++)
+            k->global_hash = ((k->global_hash << 1) | (k->global_hash >> 31)) ^ rd32(k->dst + k->op + k->offs[i] + k->sizes[f + i] - 4);
+    k->op += (size_t)total;
+    return 0;
+}
+#define COMP_PIECE_BYTES ((size_t)64 << 20)
+/* -> ZXC_OK and *op_io advanced over the nb encoded blocks, sizes[] and *hash_io filled; or a negative zxc_error_t */
+static int compress_pieces(const uint8_t* src, size_t src_size, size_t block_size, int level, int checksum_enabled, size_t tail_need,
+                           uint8_t* dst, size_t dst_capacity, size_t* op_io, uint32_t* sizes, uint32_t nb, size_t piece_bytes, uint32_t* hash_io) {
+    comp_src_t cs = {src, src_size, block_size, 0, nb};
+    comp_enq_t ce = {level, checksum_enabled};
+    comp_sink_t ck;
+    memset(&ck, 0, sizeof ck);
+    ck.dst = dst;
+    ck.dst_capacity = dst_capacity;
+    ck.op = *op_io;
+    ck.tail_need = tail_need;
+    ck.block_size = block_size;
+    ck.sizes = sizes;
+    ck.global_hash = *hash_io;
+    ck.checksum = checksum_enabled;
+    uint32_t piece_blocks = (uint32_t)(piece_bytes / block_size);
+    if (piece_blocks < 16u) piece_blocks = 16u;
+    ck.offs = (uint64_t*)malloc((size_t)piece_blocks * sizeof(uint64_t));
+    if (!ck.offs) return ZXC_ERROR_MEMORY;
+    /* (a short ramp — 16, 32, 64 MiB — so that the first encodes start while the link is still busy with the uploads behind them;
+     *  six slots: a piece's encode takes ~3.5 ms whatever its size, five of them in flight keep the chip full across their tails) */
+    const int rc = pipe_run_ex(comp_source, &cs, comp_sink, &ck, comp_enqueue, &ce, (uint32_t)block_size, 0, NULL, src_size, (uint64_t)nb * block_size,
+                               (size_t)piece_blocks * block_size, (size_t)16 << 20, 0, PIPE_SLOTS);
+    free(ck.offs);
+    if (rc != 0) return rc < 0 ? rc : ZXC_ERROR_CORRUPT_DATA;
+    *op_io = ck.op;
+    *hash_io = ck.global_hash;
     return ZXC_OK;
 }
 
@@ -891,16 +1158,16 @@ int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const 
     const uint32_t nb = (uint32_t)nb64;
     uint32_t* sizes = NULL;
     uint32_t global_hash = 0;
-    size_t batch_bytes = FRAME_BATCH_BYTES;
+    size_t batch_bytes = COMP_PIECE_BYTES;
     { const char* e = getenv("ZXC_MI355X_FRAME_BATCH_MIB"); if (e && atoi(e) >= 1 && atoi(e) <= 1024) batch_bytes = (size_t)atoi(e) << 20; }
-    const uint32_t batch_blocks = (uint32_t)(batch_bytes / block_size > 0 ? batch_bytes / block_size : 1);
-    if (nb > batch_blocks && !dict_size) { /* two batches or more: pipelined */
+    const uint32_t batch_blocks = (uint32_t)(batch_bytes / block_size > 16 ? batch_bytes / block_size : 16);
+    if (nb > batch_blocks && !dict_size) { /* two pieces or more: pipelined */
         if (zxc_mi355x_device_count() <= 0) return ZXC_ERROR_GPU_UNAVAILABLE;
         sizes = (uint32_t*)malloc((size_t)nb * sizeof(uint32_t));
         if (!sizes) return ZXC_ERROR_MEMORY;
         const size_t tail_need = BLK_HDR + (seekable ? zxc_seek_table_size(nb) : 0) + ZXC_FILE_FOOTER_SIZE;
-        const int rc = compress_batches((const uint8_t*)src, src_size, block_size, level, checksum_enabled, tail_need, dst, dst_capacity,
-                                        &op, sizes, nb, batch_blocks, &global_hash);
+        const int rc = compress_pieces((const uint8_t*)src, src_size, block_size, level, checksum_enabled, tail_need, dst, dst_capacity,
+                                       &op, sizes, nb, (size_t)batch_blocks * block_size, &global_hash);
         if (rc != ZXC_OK) { free(sizes); return rc; }
     } else if (nb > 0) {
         if (zxc_mi355x_device_count() <= 0) return ZXC_ERROR_GPU_UNAVAILABLE;
@@ -1151,70 +1418,84 @@ int64_t zxc_mi355x_plan_seekable(const zxc_seekable* s, uint32_t first, uint32_t
     return (int64_t)n;
 }
 
-/* Bytes [offset, offset + len) of the archive into dst, on the calling thread's device, arena `sub`, stream `stream`:
- * the covered blocks go to the device in batches of at most HOST_BATCH_BYTES of output slots (device memory is
- * O(batch) whatever the range), each batch = one launch over its blocks' compressed span. */
-static int64_t seek_range_on(zxc_seekable* s, uint8_t* dst, const uint64_t offset, const size_t len, int sub, void* stream) {
+/* Bytes [offset, offset + len) of the archive into dst, on the calling thread's device: the covered blocks go through the piece
+ * pipeline above (device memory is O(piece) whatever the range; upload of piece i+1 | decode | download of piece i), each piece
+ * = one launch over its blocks' compressed span. `sub`: the staging arena this caller may wait for; `slots`: how many it tries
+ * to hold. */
+typedef struct {
+    zxc_seekable* s;
+    uint32_t next, b1;
+} range_src_t;
+static int range_source(void* ctx, uint32_t max_blocks, pipe_piece_t* p) {
+    range_src_t* r = (range_src_t*)ctx;
+    zxc_seekable* s = r->s;
+    if (r->next > r->b1) return 0;
+    const uint32_t f = r->next;
+    const uint32_t n = (r->b1 - f + 1u) < max_blocks ? (r->b1 - f + 1u) : max_blocks;
+    const uint64_t c0 = s->comp_offsets[f], c1 = s->comp_offsets[f + n];
+    if (c1 > s->src_size) return ZXC_ERROR_SRC_TOO_SMALL;
+    const size_t comp_bytes = (size_t)(c1 - c0);
+    /* compressed span of the piece's blocks: borrowed buffer or reader callback (into the slot's host staging) */
+    if (s->src) {
+        p->h_comp = s->src + c0;
+    } else {
+        if (p->stage_cap < comp_bytes) {
+            free(p->stage);
+            p->stage = (uint8_t*)malloc(comp_bytes ? comp_bytes : 1);
+            p->stage_cap = p->stage ? comp_bytes : 0;
+            if (!p->stage) return ZXC_ERROR_MEMORY;
+        }
+        const int64_t got = s->reader.read_at(s->reader.ctx, p->stage, comp_bytes, c0);
+        if (got != (int64_t)comp_bytes) return got < 0 ? (int)got : ZXC_ERROR_IO;
+        p->h_comp = p->stage;
+    }
+    p->comp_bytes = comp_bytes;
+    zxc_mi355x_plan_seekable(s, f, n, c0, p->jobs);
+    /* The reference decodes each block with cap block_size + 2112 and keeps what the range needs (zxc_seekable.c:758-780):
+     * keep whole slots here. */
+    for (uint32_t k = 0; k < n; k++) p->jobs[k].out_len = s->block_size;
+    p->n = n;
+    p->out_bytes = (size_t)n * s->block_size;
+    p->cookie[0] = f;
+    r->next = f + n;
+    return 1;
+}
+typedef struct {
+    zxc_seekable* s;
+    uint8_t* dst;
+    uint64_t offset;
+    size_t len;
+} range_sink_t;
+static int range_sink(void* ctx, const pipe_piece_t* p, const int32_t* st, const dev_bufs_t* b) {
+    range_sink_t* k = (range_sink_t*)ctx;
+    zxc_seekable* s = k->s;
+    const uint32_t f = (uint32_t)p->cookie[0], n = p->n;
+    /* first failing block in job order wins (zxc_seekable.c:1097-1104) */
+    const uint64_t lo = (uint64_t)f * s->block_size; /* decoded position of the piece's first byte */
+    const uint64_t from = k->offset > lo ? k->offset : lo;
+    const uint64_t piece_end = lo + (uint64_t)n * s->block_size;
+    const uint64_t to = (k->offset + k->len) < piece_end ? (k->offset + k->len) : piece_end;
+    for (uint32_t i = 0; i < n; i++) {
+        if (st[i] < 0) return st[i];
+        /* a block that decodes short of what the range needs from it */
+        const uint64_t bstart = lo + (uint64_t)i * s->block_size;
+        const uint64_t bend = bstart + zxc_seekable_get_block_decomp_size(s, f + i);
+        const uint64_t bneed_hi = to < bend ? to : bend;
+        if (bneed_hi > bstart && (uint64_t)st[i] < bneed_hi - bstart) return ZXC_ERROR_CORRUPT_DATA;
+    }
+    if (to > from) return zxc_mi355x_memcpy_d2h(k->dst + (size_t)(from - k->offset), (const uint8_t*)b->d_out + (size_t)(from - lo), (size_t)(to - from));
+    return 0;
+}
+static int64_t seek_range_on(zxc_seekable* s, uint8_t* dst, const uint64_t offset, const size_t len, int sub, int slots) {
     const dict_ref_t dr = {s->dict, s->dict_size, s->has_dict_huf ? s->dict_huf : NULL};
     const uint32_t b0 = (uint32_t)(offset / s->block_size);
     const uint32_t b1 = (uint32_t)((offset + len - 1) / s->block_size);
-    uint32_t batch_blocks = (uint32_t)(HOST_BATCH_BYTES / s->block_size);
-    if (batch_blocks < 16u) batch_blocks = 16u;
-    const uint32_t nmax = (b1 - b0 + 1u) < batch_blocks ? (b1 - b0 + 1u) : batch_blocks;
-    zxc_dev_job_t* jobs = (zxc_dev_job_t*)malloc((size_t)nmax * sizeof(*jobs));
-    int32_t* st = (int32_t*)malloc((size_t)nmax * sizeof(int32_t));
-    uint8_t* staged = NULL;
-    size_t staged_cap = 0;
-    int64_t ret = (jobs && st) ? (int64_t)len : (int64_t)ZXC_ERROR_MEMORY;
-    for (uint32_t f = b0; ret >= 0 && f <= b1; f += nmax) {
-        const uint32_t n = (b1 - f + 1u) < nmax ? (b1 - f + 1u) : nmax;
-        const uint64_t c0 = s->comp_offsets[f], c1 = s->comp_offsets[f + n];
-        if (c1 > s->src_size) { ret = ZXC_ERROR_SRC_TOO_SMALL; break; }
-        const size_t comp_bytes = (size_t)(c1 - c0);
-        /* compressed span of the batch's blocks: borrowed buffer or reader callback */
-        const uint8_t* h_comp;
-        if (s->src) {
-            h_comp = s->src + c0;
-        } else {
-            if (staged_cap < comp_bytes) {
-                free(staged);
-                staged = (uint8_t*)malloc(comp_bytes ? comp_bytes : 1);
-                staged_cap = staged ? comp_bytes : 0;
-                if (!staged) { ret = ZXC_ERROR_MEMORY; break; }
-            }
-            const int64_t r = s->reader.read_at(s->reader.ctx, staged, comp_bytes, c0);
-            if (r != (int64_t)comp_bytes) { ret = r < 0 ? r : (int64_t)ZXC_ERROR_IO; break; }
-            h_comp = staged;
-        }
-        zxc_mi355x_plan_seekable(s, f, n, c0, jobs);
-        /* The reference decodes each block with cap block_size + 2112 and keeps what
-         * the range needs (zxc_seekable.c:758-780): keep whole slots here. */
-        for (uint32_t k = 0; k < n; k++) jobs[k].out_len = s->block_size;
-        dev_bufs_t b;
-        const int rc = run_jobs_on(h_comp, comp_bytes, jobs, n, (size_t)n * s->block_size, s->block_size, 0u, 0, st, &b, &dr, sub, stream);
-        if (rc != ZXC_OK) { ret = rc; break; }
-        /* first failing block in job order wins (zxc_seekable.c:1097-1104) */
-        const uint64_t lo = (uint64_t)f * s->block_size;                 /* decoded position of the batch's first byte */
-        const uint64_t from = offset > lo ? offset : lo;
-        const uint64_t batch_end = lo + (uint64_t)n * s->block_size;
-        const uint64_t to = (offset + len) < batch_end ? (offset + len) : batch_end;
-        for (uint32_t k = 0; k < n; k++) {
-            if (st[k] < 0) { ret = st[k]; break; }
-            /* a block that decodes short of what the range needs from it */
-            const uint64_t bstart = lo + (uint64_t)k * s->block_size;
-            const uint64_t bneed_hi = to < bstart + zxc_seekable_get_block_decomp_size(s, f + k) ? to : bstart + zxc_seekable_get_block_decomp_size(s, f + k);
-            if (bneed_hi > bstart && (uint64_t)st[k] < bneed_hi - bstart) { ret = ZXC_ERROR_CORRUPT_DATA; break; }
-        }
-        if (ret >= 0 && to > from) {
-            const int crc = dev_bufs_read(&b, dst + (size_t)(from - offset), (size_t)(from - lo), (size_t)(to - from));
-            if (crc != ZXC_OK) ret = crc;
-        }
-        dev_bufs_free(&b);
-    }
-    free(jobs);
-    free(st);
-    free(staged);
-    return ret;
+    range_src_t src = {s, b0, b1};
+    range_sink_t snk = {s, dst, offset, len};
+    const uint64_t comp_span = s->comp_offsets[b1 + 1u] - s->comp_offsets[b0];
+    const int rc = pipe_run(range_source, &src, range_sink, &snk, s->block_size, 0, &dr, (size_t)comp_span,
+                            (uint64_t)(b1 - b0 + 1u) * s->block_size, 0, sub, slots);
+    return rc < 0 ? (int64_t)rc : (int64_t)len;
 }
 
 static int64_t seek_range_check(zxc_seekable* s, void* dst, const size_t dst_capacity, const uint64_t offset, const size_t len) {
@@ -1230,7 +1511,7 @@ int64_t zxc_seekable_decompress_range(zxc_seekable* s, void* dst, const size_t d
     if (len == 0) return 0;
     const int64_t chk = seek_range_check(s, dst, dst_capacity, offset, len);
     if (chk < 0) return chk;
-    return seek_range_on(s, (uint8_t*)dst, offset, len, 0, NULL);
+    return seek_range_on(s, (uint8_t*)dst, offset, len, 0, PIPE_DECODE_SLOTS);
 }
 
 /* The multi-threaded range decode (reference: zxc_seekable.c:1033-1108 plans one job per block and lets n_threads workers
@@ -1250,13 +1531,12 @@ typedef struct {
 } seek_part_t;
 static void* seek_part_main(void* p) {
     seek_part_t* a = (seek_part_t*)p;
-    void* stream = NULL;
-    if (zxc_mi355x_set_device(a->device) != ZXC_OK || zxc_hip_stream_create(&stream) != ZXC_OK) {
+    if (zxc_mi355x_set_device(a->device) != ZXC_OK) {
         a->result = ZXC_ERROR_GPU_UNAVAILABLE;
         return NULL;
     }
-    a->result = seek_range_on(a->s, a->dst, a->offset, a->len, a->sub, stream);
-    zxc_hip_stream_destroy(stream);
+    /* (each part runs its own piece pipeline: its own stream, the arena of its `sub` + one more if one is free) */
+    a->result = seek_range_on(a->s, a->dst, a->offset, a->len, a->sub, 2);
     return NULL;
 }
 static int device_list(int* devs, int cap) {
