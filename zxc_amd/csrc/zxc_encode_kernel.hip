@@ -589,6 +589,22 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
             pos = next_pos;
             ENC_T(7);  // emission
         }
+#ifdef EXP_ENC_EXTRA_SALU  // experiment only: EXP_ENC_EXTRA_SALU scalar instructions per chunk (is the encoder scalar-issue-bound?)
+        {
+            uint32_t sd = c0;
+#pragma unroll
+            for (int q = 0; q < EXP_ENC_EXTRA_SALU; q++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sd) : : "scc");
+            asm volatile("" ::"s"(sd));
+        }
+#endif
+#ifdef EXP_ENC_EXTRA_VALU  // experiment only: EXP_ENC_EXTRA_VALU vector instructions per chunk
+        {
+            uint32_t vd = (uint32_t)lane;
+#pragma unroll
+            for (int q = 0; q < EXP_ENC_EXTRA_VALU; q++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(vd));
+            asm volatile("" ::"v"(vd));
+        }
+#endif
         // a match reaching past these chunks: skip the chunks it covers entirely
         c0 += 64u * U;
         if (pos > c0) c0 = pos & ~63u;
