@@ -289,6 +289,31 @@ def encode_run(args, level, enc_mib, steps, warmup, comm, with_cpu_baseline=True
                      "kernel": f"zxc_encode_blocks_kernel_{entry}", "avg_launch_ms": round(kern_s * 1e3, 4),
                      "algorithmic_bytes_per_launch": algo},
         "round_trip": {"device": f"all {nb} blocks decoded on the device == source", "reference": ref_ok}}
+    # incompressible input (where the reference's match finder accelerates its steps, src/lib/zxc_compress.c:1176): 256 MiB of random bytes,
+    # every block must come out RAW (stored: 8-byte header + the bytes) and decode back
+    try:
+        rn = 256 << 20
+        d_rnd = torch.randint(0, 256, (rn + 256,), dtype=torch.uint8, device=dev)
+        rnb = rn // bs
+        def rstep():
+            assert L.zxc_mi355x_encode_blocks_device(C.c_void_p(d_rnd.data_ptr()), rn, bs, level, 0, C.c_void_p(d_slots.data_ptr()),
+                                                     C.c_void_p(d_sizes.data_ptr()), C.c_void_p(stream)) == 0
+        rstep(); torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); rstep(); rstep(); e1.record(); torch.cuda.synchronize()
+        rms = e0.elapsed_time(e1) / 2
+        raw_ok = bool((d_sizes[:rnb] == bs + 8).all().item())
+        slots = d_slots[:rnb * stride].view(rnb, stride)
+        raw_ok = raw_ok and torch.equal(slots[:, 8:8 + bs].reshape(-1), d_rnd[:rn])
+        line["incompressible"] = {"value": round(rn / rms / 1e6, 1), "unit": "GB/s of source", "bytes": rn, "ms": round(rms, 3),
+                                  "all_blocks_raw_and_equal_to_the_source": raw_ok,
+                                  "what": "256 MiB of random bytes: after 8 chunks (512 B) without a sequence only every fourth chunk of 64 positions is searched"}
+        assert raw_ok, "incompressible blocks must be stored RAW"
+        del d_rnd
+    except AssertionError:
+        raise
+    except Exception as ex:  # (never lose the line over the extra measurement)
+        line["incompressible"] = {"error": repr(ex)}
     if with_cpu_baseline and world == 1 and oracle_py.Ref.available():
         line["cpu_baseline"] = cpu_baseline_encode(sample, level, bs)
     return line
@@ -493,7 +518,15 @@ def decode_run(args, level, tiles, steps, warmup, comm, checksum=False, calib_la
         cfg += f" at the reference's {'default' if bs == 524288 else 'maximum' if bs == 2097152 else 'other'} block size"
     if world > 1 or strong:
         cfg = f"configs[3] ({all_tiles * 211943424 / 2**30:.1f} GiB corpus over {world} GPUs, {'strong' if strong else 'weak'} scaling)"
-    traffic = profiled_traffic("decode_l%d" % level, tiles=tiles, block_size=bs) if not (checksum or strong) else None
+    traffic = None
+    if not (checksum or strong or world > 1):
+        if getattr(args, "live_traffic", False) and level == 3:
+            del d_comp, d_want, d_out  # (the child needs a few GB of its own; this run's device buffers are done)
+            torch.cuda.empty_cache()
+            d_comp = d_want = d_out = None
+            traffic = measure_traffic_live(level, bs, n_jobs, algo_bytes)
+        if traffic is None:
+            traffic = profiled_traffic("decode_l%d" % level, tiles=tiles, block_size=bs)
     line = {
         "metric": f"seekable decode GB/s (level {level}, {bs >> 10} KiB independent blocks, HBM-resident in/out"
                   + (", per-block checksums verified on the device)" if checksum else ")"),
@@ -521,7 +554,7 @@ def decode_run(args, level, tiles, steps, warmup, comm, checksum=False, calib_la
     if with_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(tile0_comp, int.from_bytes(tile0_comp[-12:-4], "little"), cpu_budget_s,
                                             f"corpus tiles 0-{base_tiles - 1} as one archive" if base_tiles > 1 else "corpus tile 0")
-    del d_comp, d_want, d_out
+    d_comp = d_want = d_out = None
     torch.cuda.empty_cache()
     return line
 
@@ -541,11 +574,11 @@ def kernel_sources_hash():
 def profiled_traffic(what, **workload):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (FETCH_SIZE / WRITE_SIZE in
     separate --pmc runs, counters corrected as profiles/r3_gather_calibration.log prescribes; tools/profile.sh +
-    tools/profile_summary.py write profiles/r4_traffic.json). NOT measured in this run: a constant, reported only when the
+    tools/profile_summary.py write profiles/r5_traffic.json). NOT measured in this run: a constant, reported only when the
     run's workload equals the profiled one AND the device sources are byte for byte the ones that were profiled
     (`kernels` = kernel_sources_hash() at profiling time) — else null, never a stale number (VERDICT r3 weak #5)."""
     try:
-        tab = json.load(open(os.path.join(ROOT, "profiles", "r4_traffic.json")))
+        tab = json.load(open(os.path.join(ROOT, "profiles", "r5_traffic.json")))
         e = tab.get(what)
         if e and e.get("kernels") == kernel_sources_hash() and all(e["workload"].get(k) == v for k, v in workload.items()):
             return {"bytes_per_launch": e["bytes_per_launch"], "read": e["read"], "write": e["write"], "source": e["source"],
@@ -553,6 +586,66 @@ def profiled_traffic(what, **workload):
     except Exception:
         pass
     return None
+
+
+def measure_traffic_live(level, bs, n_blocks, algo_bytes):
+    """HBM bytes per launch measured IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE: they do not
+    fit one pass, MI355X_MICROARCH.md) over a child process that decodes a 10-tile corpus with the same library on this box; the decode
+    kernels' counters of the timed launches, corrected as tools/profile_summary.py does (FETCH_SIZE counts requests x 64 B: x 1.107 for
+    this kernel's single-sector gathers, profiles/r3_gather_calibration.log; WRITE_SIZE as counted), per block x this run's blocks
+    (traffic per block does not depend on the launch's size beyond the caches: 10 tiles = 2.1 GB decoded >> 256 MiB Infinity Cache).
+    -> dict, or None when rocprofv3 is not there / a pass fails (the caller then falls back to the committed table)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get("ZXC_BENCH_LIVE_TRAFFIC", "1") == "0" or not shutil.which("rocprofv3"):
+        return None
+    kernels = ("zxc_decode_blocks_lean_kernel", "zxc_decode_blocks_kernel", "zxc_decode_blocks_lean_pre_kernel", "zxc_rle_expand_kernel",
+               "zxc_pivco_sections_small_kernel", "zxc_pivco_sections_medium_kernel", "zxc_pivco_sections_large_kernel")
+    child_tiles, steps = 10, 3
+    got, child_blocks = {}, None
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="zxc_traffic_", dir="/tmp")
+            env = dict(os.environ, ZXC_BENCH_LIVE_TRAFFIC="0", TMPDIR="/tmp")
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+            cmd = ["rocprofv3", "--pmc", ctr, "-d", d, "-o", "t", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+                   "--tiles", str(child_tiles), "--steps", str(steps), "--warmup", "2", "--no-secondary", "--no-cpu-baseline", "--calib",
+                   "--level", str(level), "--block-size", str(bs)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            line = next((json.loads(x) for x in r.stdout.splitlines() if x.startswith("{") and '"metric"' in x), None)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or line is None or not files:
+                return None
+            child_blocks = line["config"]["blocks_per_gpu"]
+            per = {}
+            for row in csv.DictReader(open(files[0])):
+                k = row["Kernel_Name"].split("(")[0].strip()
+                if k in kernels and row["Counter_Name"] == ctr:
+                    per.setdefault(k, {}).setdefault(int(row["Dispatch_Id"]), 0.0)
+                    per[k][int(row["Dispatch_Id"])] += float(row["Counter_Value"])
+            tot = 0.0
+            for k, dd in per.items():  # dispatches of a kernel: [calibration, 2 warm-up, `steps` timed, 1 re-check]
+                ids = sorted(dd)
+                ids = ids[-(steps + 1):-1] if len(ids) >= steps + 1 else []
+                if ids:
+                    tot += sum(dd[i] for i in ids) / len(ids)
+            got[ctr] = tot * 1024.0  # (the counters are in KiB)
+            shutil.rmtree(d, ignore_errors=True)
+    except Exception:
+        return None
+    if not got.get("FETCH_SIZE") or not got.get("WRITE_SIZE") or not child_blocks:
+        return None
+    scale = n_blocks / child_blocks
+    read, write = got["FETCH_SIZE"] * 1.107 * scale, got["WRITE_SIZE"] * scale
+    return {"bytes_per_launch": int(read + write), "read": int(read), "write": int(write), "over_algorithmic": round((read + write) / algo_bytes, 3),
+            "measured_in_this_run": True, "kernels": kernel_sources_hash(),
+            "how": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one pass each) around a child process decoding a {child_tiles}-tile corpus "
+                   f"({child_blocks} blocks) with this library on this box; decode kernels of the timed launches; FETCH_SIZE x 1.107 "
+                   f"(single-sector gathers, profiles/r3_gather_calibration.log), per block x {n_blocks} blocks"}
 
 
 def host_api_run(args, dev):
@@ -575,10 +668,7 @@ def host_api_run(args, dev):
     L.zxc_compress.restype = C.c_int64
     L.zxc_decompress.restype = C.c_int64
 
-    class COpts(C.Structure):  # include/zxc_opts.h (reference include/zxc_opts.h:58-78)
-        _fields_ = [("n_threads", C.c_int), ("level", C.c_int), ("block_size", C.c_size_t), ("checksum_enabled", C.c_int),
-                    ("seekable", C.c_int), ("dict", C.c_void_p), ("dict_size", C.c_size_t), ("dict_huf", C.c_void_p),
-                    ("progress_cb", C.c_void_p), ("user_data", C.c_void_p)]
+    COpts = zxc_amd.api._CompressOpts  # include/zxc_opts.h (reference include/zxc_opts.h:58-78)
     L.zxc_compress.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(COpts)]
     L.zxc_decompress.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     o = COpts(level=3, block_size=bs, seekable=1)
@@ -622,6 +712,7 @@ def host_api_run(args, dev):
             res[name] = {"value": round(len(t0d) / dt / 1e9, 2), "unit": "GB/s decoded", "ms": round(dt * 1e3, 1),
                          "archive": f"corpus tile 0 written by the reference ({len(t0d) >> 20} MiB decoded)", "checked": "every byte"}
         sk.close()
+    L.zxc_decompress.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(zxc_amd.api._DecompressOpts)]  # (as zxc_amd.api binds it)
     return res
 
 
@@ -770,8 +861,11 @@ def main():
         if args.mode == "encode":
             line = encode_run(args, args.level, args.enc_mib, args.steps, args.warmup, comm, not args.no_cpu_baseline)
         else:
+            # (the headline line of the default run measures its HBM traffic itself: two short rocprofv3 passes in a child process)
+            args.live_traffic = world == 1 and args.level == 3 and not args.checksum and not args.calib and not args.no_secondary and args.block_size == 65536
             line = decode_run(args, args.level, args.tiles, args.steps, args.warmup, comm, args.checksum, args.calib,
                               not args.no_cpu_baseline)
+            args.live_traffic = False
             # The default single-GPU run also measures the other two single-GPU configurations of BASELINE.json, each with its
             # own roofline / cpu_baseline objects and its own bit-exactness check (next #2).
             if world == 1 and args.level == 3 and not args.checksum and not args.calib and not args.no_secondary:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condense the rocprofv3 CSV outputs of tools/profile.sh (gpurun_out/<tag>_{kt,fetch,write,sq,tcp}) into
-profiles/<tag>_summary.json + <tag>_kernel_stats.csv, and enter the launch's HBM traffic into profiles/r4_traffic.json
+profiles/<tag>_summary.json + <tag>_kernel_stats.csv, and enter the launch's HBM traffic into profiles/r5_traffic.json
 (the table bench.py's roofline.traffic is read from) together with the content hash of the device sources that were profiled
 (bench.kernel_sources_hash(): bench.py reports the traffic only while that hash still matches its own tree).
 
@@ -119,7 +119,7 @@ if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
         algo = bench["roofline"]["algorithmic_bytes_per_launch"]
         out["hbm_traffic_bytes_per_launch"]["over_algorithmic"] = round((read + raw_w) / algo, 3)
         # the table bench.py reads
-        tp = os.path.join(P, "r4_traffic.json")
+        tp = os.path.join(P, "r5_traffic.json")
         tab = json.load(open(tp)) if os.path.exists(tp) else {}
         cfg = bench["config"]
         if what == "decode":

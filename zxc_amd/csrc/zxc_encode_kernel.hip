@@ -45,6 +45,7 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 // The head table + chain ring are the LDS footprint, i.e. the occupancy (sizes per level: table at the bottom;
 // measured trade-offs: profiles/r2o_encode_table_sizes_ab.log).
 #define ENC_MARGIN 8u   // the last 8 bytes of a block never start a match (reference ZXC_LZ_SEARCH_MARGIN)
+#define ENC_DRY_CHUNKS 8u   // chunks of 64 positions without a sequence before the match finder starts skipping (skip acceleration, below)
 // Table entries are the low 16 bits of a position: offsets are < 65536 anyway, so the candidate is
 // i - ((i - entry) & 0xFFFF); a stale or never-written entry just names some older position, and
 // every candidate is verified against the bytes. Half the LDS of 32-bit entries -> twice the waves.
@@ -219,6 +220,11 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
 #endif
     uint32_t* const mp = OPT ? (uint32_t*)(huf_scratch + (uint64_t)b * 4u * ((uint64_t)block_size + 64u)) : nullptr;
     uint32_t skip_until = 0;  // OPT: positions below it lie strictly inside a match of >= OPT_LONG_SKIP bytes and are not searched
+    // Skip acceleration (round 5; reference: step = step_base + (distance from the anchor >> step_shift), src/lib/zxc_compress.c:1176, :1860 —
+    // the CPU walks incompressible input in growing steps). Here a chunk is the unit: after ENC_DRY_CHUNKS chunks in a row without a
+    // single sequence (512 bytes of literals) only every fourth chunk fetches and compares candidates, the others just enter their
+    // positions into the tables (lookup + publish: a quarter of a chunk's cost); the first sequence found ends it. Text never gets there.
+    uint32_t dry = 0;  // chunks in a row in which the parse selected nothing
     uint32_t seq_count = 0, lit_count = 0, ext_count = 0, max_off = 0;
     uint32_t pos = D;     // next position the parse will look at
     uint32_t anchor = D;  // end of the last emitted match
@@ -329,7 +335,10 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
 #ifdef EXP_ENC_WALK_ALL
         for (uint32_t u = 0; u < U; u++) { lenA[u] = 0; distA[u] = 0; triedA[u] = 0; dA[u] = d0A[u]; }
 #else
-        for (uint32_t u = 0; u < U; u++) { lenA[u] = 0; distA[u] = 0; triedA[u] = 0; dA[u] = (OPT || iA[u] >= pos) ? d0A[u] : 0u; }
+        for (uint32_t u = 0; u < U; u++) {
+            const bool skip = !OPT && dry >= ENC_DRY_CHUNKS && (((c0 >> 6) + u) & 3u) != 0u;  // (wave-uniform)
+            lenA[u] = 0; distA[u] = 0; triedA[u] = 0; dA[u] = ((OPT || iA[u] >= pos) && !skip) ? d0A[u] : 0u;
+        }
 #endif
 #ifdef EXP_ENC_NOWALK  // (experiment, wrong output: no candidate is fetched or compared — lookup, publish, parse and emission only)
         for (uint32_t u = 0; u < U; u++) dA[u] = 0;
@@ -581,6 +590,8 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     #endif
             lit_count += __popcll(litmask);
             seq_count += nsel;
+            // (a chunk of literals only: one inside a long match says nothing about what follows it)
+            dry = nsel ? 0u : ((__popcll(litmask) >= 48 && dry < 0xFFFFu) ? dry + 1u : dry);
             ext_count += etot;
             if (sel) {
                 const int last = 63 - __builtin_clzll(sel);
