@@ -590,8 +590,7 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
     #endif
             lit_count += __popcll(litmask);
             seq_count += nsel;
-            // (a chunk of literals only: one inside a long match says nothing about what follows it)
-            dry = nsel ? 0u : ((__popcll(litmask) >= 48 && dry < 0xFFFFu) ? dry + 1u : dry);
+            dry = nsel ? 0u : dry + 1u;  // (also counts the chunks inside a long match: behind one, up to three chunks go unsearched until the next sequence — rare, and three scalar instructions here instead of nine)
             ext_count += etot;
             if (sel) {
                 const int last = 63 - __builtin_clzll(sel);
