@@ -48,6 +48,8 @@ def counters(path, skip_first):
                 # five timed ones if in any: the five dispatches in front of its last
                 calib[c] = calib.get(c, 0.0) + d[ids[0]]
                 ids = ids[-6:-1] if len(ids) >= 6 else []
+            if what == "encode":  # bench.py --mode encode --warmup 1 --steps 5: [warm-up, 5 timed] over the text; the launches behind them are its incompressible-input leg
+                ids = ids[1:6]
             if ids:
                 tot += sum(d[i] for i in ids) / len(ids)
                 n = max(n, len(ids))
