@@ -26,7 +26,8 @@ static void zxc_encode_dispatch(int level, const uint8_t* src, uint64_t src_size
         case 1: zxc_encode_blocks_kernel_l2(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size, hs, p.huf); break;
         case 2: zxc_encode_blocks_kernel_l3(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size, hs, p.huf); break;
         case 3: zxc_encode_blocks_kernel_l4(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size, hs, p.huf); break;
-        default: zxc_encode_blocks_kernel_l57(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size, hs, p.huf); break;
+        case 4: zxc_encode_blocks_kernel_l57(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size, hs, p.huf); break;
+        default: zxc_encode_blocks_kernel_l67(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size, hs, p.huf); break;
     }
 }
 

@@ -851,15 +851,15 @@ __device__ __forceinline__ void encode_one_block(const uint8_t* __restrict__ src
 // sufficient_len 16/18/16/18/256/256/256, lazy probes 0/0/1/1(+ip+2)/1(+ip+2)/0/0; levels 1-2 emit GHI and use
 // the 4-byte hash, levels >= 3 GLO and the 5-byte hash. Here every position is inserted, so chains are denser
 // than the CPU's and the deep levels walk fewer links for the same reach; LDS per wave (= occupancy) grows with
-// the level: 8 / 12 / 20 / 24 / 48 / 48 / 48 KiB.
+// the level: 8 / 12 / 20 / 24 / 48 / 80 / 80 KiB.
 //   level   head   chain ring   depth   candidates per round   sufficient   parse     block type
 //     1     2^12      -           1          3                    16        greedy    GHI
 //     2     2^12     2^11         3          3                    18        greedy    GHI
 //     3     2^13     2^11         4          4                    16        lazy 2    GLO
 //     4     2^13     2^12         6          6                    18        lazy 2    GLO
 //     5     2^13     2^14        18          6                   256        lazy 2    GLO
-//     6     2^13     2^14        33          6                   256        optimal   GLO + PivCo literals (zxc_optparse.inc)
-//     7     2^13     2^14        66          6                   256        lazy 2    GLO + PivCo literals and tokens
+//     6     2^13     2^15        33          6                   256        optimal   GLO + PivCo literals (zxc_optparse.inc)
+//     7     2^13     2^15        66          6                   256        lazy 2    GLO + PivCo literals and tokens
 #ifndef ENC_U
 #define ENC_U 1u   // chunks of 64 positions in flight per loop iteration (A/B, profiles/r3p_encu.log: 1 / 2 / 3 / 4 all within 2 % at
                    // level 3 — a wave issues in order, only the memory round trips overlap — and 1 keeps the archives of round 2 byte for byte)
@@ -896,7 +896,15 @@ ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l4, (1u << ENC_L4_HB), ENC_L4_CWB, fal
 #ifndef ENC_L57_NC
 #define ENC_L57_NC 6u   // candidates per round of the deep levels (18 / 33 / 66 per position: half the round trips of 3)
 #endif
-ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l57, (1u << ENC_L57_HB), ENC_L57_CWB, false, 1, ENC_L57_NC) // levels 5-7
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l57, (1u << ENC_L57_HB), ENC_L57_CWB, false, 1, ENC_L57_NC) // level 5
+// Levels 6-7 (round 5): a chain ring of 2^15 entries. The reference's chain reaches 65 536 positions back (ZXC_LZ_WINDOW_SIZE,
+// src/lib/zxc_common.c:199); with 2^14 the ultra levels came out 2.2-2.5 % larger than the reference's on text, with 2^15 0.8-0.9 %
+// (2^16: 0.3 %, but 144 KiB of tables = one workgroup per CU): 80 KiB of tables = two workgroups per CU instead of three —
+// the ultra tiers buy ratio with speed (tests/test_wave_emu.py, profiles/r5f_*).
+#ifndef ENC_L67_CWB
+#define ENC_L67_CWB 15u
+#endif
+ZXC_ENCODE_ENTRY(zxc_encode_blocks_kernel_l67, (1u << ENC_L57_HB), ENC_L67_CWB, false, 1, ENC_L57_NC) // levels 6-7
 
 // [dict | block b] images for the dictionary path: work + b * (block_size + dict_size)
 extern "C" __global__ void __launch_bounds__(64)

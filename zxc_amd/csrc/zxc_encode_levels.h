@@ -3,7 +3,7 @@
 #ifndef ZXC_ENCODE_LEVELS_H
 #define ZXC_ENCODE_LEVELS_H
 #include <stdint.h>
-/* entry: 0 l1, 1 l2, 2 l3, 3 l4, 4 l57 (zxc_encode_blocks_kernel_*) */
+/* entry: 0 l1, 1 l2, 2 l3, 3 l4, 4 l57 (level 5), 5 l67 (levels 6-7: the 2^15-entry chain ring) (zxc_encode_blocks_kernel_*) */
 typedef struct { int entry; uint32_t depth, sufficient, lazy, huf; } zxc_enc_level_t; /* huf: 0 none, 1 PivCo literals, 2 + tokens */
 #define ZXC_ENC_PARSE_OPTIMAL 3u /* `lazy` value: no lazy probes, the price-based optimal parse (zxc_optparse.inc) picks the sequences */
 static inline zxc_enc_level_t zxc_enc_level(int level) {
@@ -14,8 +14,8 @@ static inline zxc_enc_level_t zxc_enc_level(int level) {
         {2, 4, 16, 2, 0},    /* 3: the 20 KiB entry, four candidates in one round */
         {3, 6, 18, 2, 0},    /* 4 */
         {4, 18, 256, 2, 0},  /* 5 */
-        {4, 33, 256, ZXC_ENC_PARSE_OPTIMAL, 1},  /* 6: optimal parse + PivCo-coded literal section */
-        {4, 66, 256, 2, 2},  /* 7: + PivCo-coded token section. Lazy parse: with 66 candidates per position the optimal parse measured
+        {5, 33, 256, ZXC_ENC_PARSE_OPTIMAL, 1},  /* 6: optimal parse + PivCo-coded literal section */
+        {5, 66, 256, 2, 2},  /* 7: + PivCo-coded token section. Lazy parse: with 66 candidates per position the optimal parse measured
                               *    the same sizes (+-0.15 %) for 0.64 x the speed (profiles/r4g_optimal_parse.log) */
     };
     return t[level < 1 ? 1 : (level > 7 ? 7 : level)];

@@ -10,7 +10,7 @@
 #ifndef ZXC_EXPERIMENT
 #if defined(ABL_ALL_NEAR) || defined(ABL_NO_DEPS) || defined(ABL_NO_FARPUT) || defined(ABL_NO_FARTAIL) || defined(ABL_NO_FLUSH) || \
     defined(ABL_NO_LIT) || defined(ABL_NO_LITTAIL) || defined(ABL_NO_NEAR) || defined(ASM_MARKERS) || defined(ENC_ALIGNED_CANDIDATES) || \
-    defined(ENC_L3_HB) || defined(ENC_L4_HB) || defined(ENC_L57_HB) || defined(ENC_L57_NC) || defined(ENC_U) || defined(EXP_ENC_CLOCKS) || \
+    defined(ENC_L3_HB) || defined(ENC_L4_HB) || defined(ENC_L57_HB) || defined(ENC_L57_NC) || defined(ENC_L67_CWB) || defined(ENC_U) || defined(EXP_ENC_CLOCKS) || \
     defined(EXP_ENC_ENV) || defined(EXP_ENC_EXTRA_SALU) || defined(EXP_ENC_EXTRA_VALU) || defined(EXP_ENC_NOPARSE) || defined(EXP_ENC_NOSTORE) || defined(EXP_ENC_NOWALK) || defined(EXP_ENC_WALK_ALL) || \
     defined(EXP_EXTRA_SLEEP) || defined(EXP_EXTRA_VMEM) || defined(EXP_EXTRA_SALU) || defined(EXP_EXTRA_VALU) || defined(EXP_NO_FAR) || defined(EXP_NO_OPTPARSE) || defined(EXP_NO_PIV_LDS) || \
     defined(EXP_NO_PRE) || defined(EXP_NT_FAR) || defined(EXP_NT_LIT) || defined(EXP_OPTPARSE_L7) || defined(EXP_PDIR_BADOUT) || \

@@ -65,6 +65,7 @@ ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l2)
 ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l3)
 ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l4)
 ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l57)
+ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l67)
 extern "C" __global__ void zxc_prepend_dict_kernel(const uint8_t* src, uint64_t src_size, uint32_t block_size, const uint8_t* dict,
                                                    uint32_t dict_size, uint8_t* work, uint32_t n_blocks);
 extern "C" __global__ void zxc_block_offsets_kernel(uint32_t* sizes, uint64_t* offsets, uint32_t n_blocks, uint32_t max_size);
@@ -548,7 +549,8 @@ static int encode_launch(const void* d_src, uint64_t src_size, uint32_t block_si
         if (hipMallocAsync((void**)&huf_scratch, need, (hipStream_t)stream) != hipSuccess || !huf_scratch) return ZXC_ERROR_MEMORY;
     }
     auto kern = lp.entry == 0 ? zxc_encode_blocks_kernel_l1 : lp.entry == 1 ? zxc_encode_blocks_kernel_l2
-              : lp.entry == 2 ? zxc_encode_blocks_kernel_l3 : lp.entry == 3 ? zxc_encode_blocks_kernel_l4 : zxc_encode_blocks_kernel_l57;
+              : lp.entry == 2 ? zxc_encode_blocks_kernel_l3 : lp.entry == 3 ? zxc_encode_blocks_kernel_l4
+              : lp.entry == 4 ? zxc_encode_blocks_kernel_l57 : zxc_encode_blocks_kernel_l67;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64), 0, (hipStream_t)stream, in, src_size, block_size,
                        (uint8_t*)d_slots, zxc_mi355x_encode_slot_stride(block_size), d_sizes, nb, with_checksum ? 1u : 0u,
                        lp.depth, lp.sufficient, lp.lazy, dict_size, huf_scratch, lp.huf);
