@@ -160,6 +160,8 @@ extern "C" __global__ void zxc_enc_clk_read_kernel(unsigned long long* out) {
 }
 #define ENC_T(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t t_ = __builtin_readcyclecounter(); \
                       clk_acc[k] += t_ - clk_last; clk_last = t_; } while (0)
+#elif defined(ASM_MARKERS)  // (design builds: tools/isacount.py counts the instructions between these comments)
+#define ENC_T(k) asm volatile("; PHMARK " #k)
 #else
 #define ENC_T(k) do { } while (0)
 #endif
