@@ -7,5 +7,6 @@
 #include "zxc_buffer.h"
 #include "zxc_seekable.h"
 #include "zxc_dict.h"
+#include "zxc_pstream.h"
 #include "zxc_mi355x.h"
 #endif

@@ -1,6 +1,6 @@
 /* subset_main.c — runs the reference's own unit-test functions (compiled in place from /root/reference/tests/*.c, see the
  * Makefile) against libzxc_mi355x.so. Test infrastructure. The case list is the public-API part of the reference's table
- * (tests/test_main.c:60-64 Block API, :50-58 Buffer API, :66-69 contexts, :144-172 seekable); each function returns 1 on
+ * (tests/test_main.c:60-64 Block API, :50-58 Buffer API, :66-69 contexts, :144-172 seekable, :90-104 push streaming); each function returns 1 on
  * success like there. Usage: zxc_unit_subset [--list] [name-substring]. Prints "RESULT name PASS|FAIL" per case. */
 #include <stdio.h>
 #include <string.h>
@@ -25,6 +25,13 @@ static const test_entry_t g_tests[] = {
     TEST_CASE(test_seekable_cross_boundary), TEST_CASE(test_seekable_truncated_input), TEST_CASE(test_seekable_corrupted_sek),
     TEST_CASE(test_seekable_range_out_of_bounds), TEST_CASE(test_seekable_dst_too_small), TEST_CASE(test_seekable_empty_file),
     TEST_CASE(test_seekable_no_checksum), TEST_CASE(test_seekable_with_checksum), TEST_CASE(test_seekable_work_buf_tail_pad),
+    /* push streaming, tests/test_main.c:90-104 */
+    TEST_CASE(test_pstream_roundtrip_basic), TEST_CASE(test_pstream_roundtrip_no_checksum), TEST_CASE(test_pstream_roundtrip_levels),
+    TEST_CASE(test_pstream_tiny_chunks), TEST_CASE(test_pstream_drip_one_byte), TEST_CASE(test_pstream_empty_input),
+    TEST_CASE(test_pstream_large_random), TEST_CASE(test_pstream_compatible_with_buffer_api),
+    TEST_CASE(test_pstream_decompress_compatible_with_buffer_api), TEST_CASE(test_pstream_invalid_args),
+    TEST_CASE(test_pstream_truncated_input), TEST_CASE(test_pstream_corrupted_magic), TEST_CASE(test_pstream_decode_seekable_archive),
+    TEST_CASE(test_pstream_compress_after_end_rejected), TEST_CASE(test_pstream_compress_drain_block_resume),
 };
 
 int main(int argc, char** argv) {

@@ -69,3 +69,15 @@ def load_dict(path):
 
 def read(rel):
     return open(os.path.join(GOLDEN, rel), "rb").read()
+
+
+@pytest.fixture(scope="session")
+def mockdev(ref):
+    """The product's HOST sources over a mock device (host memory + the reference's Block API): tests/mock_device. -> CDLL"""
+    import ctypes
+    import subprocess
+    d = os.path.join(ROOT, "tests", "mock_device")
+    subprocess.run(["make", "-C", d], check=True, capture_output=True)
+    L = ctypes.CDLL(os.path.join(d, "_bin", "libzxc_mockdev.so"))
+    assert L.zxc_mi355x_device_count() == 1
+    return L

@@ -1,0 +1,168 @@
+"""The HOST side of the library without a GPU: zxc_amd/csrc/zxc_host.c (and what it includes) compiled over tests/mock_device — a
+"device" of host memory whose two kernels are the UNMODIFIED reference's Block API. What runs here is the product's own framing,
+batching, error precedence and state machines (push streaming, the piece pipeline of zxc_decompress / zxc_compress / the
+seekable ranges); since the block codec underneath is the reference's, archives must be BYTE FOR BYTE the reference's and every
+verdict the reference's. The same properties on the real device: tests/test_gpu_pstream.py, tests/test_gpu_pipeline.py."""
+import random
+
+import pytest
+
+import zxc_amd.api as api
+
+CHUNKINGS = ((1 << 30, 1 << 30), (8192, 8192), (13 * 1024, 700), (511, 7000), (137, 53), (1, 4096))
+
+
+def _text(rng, n, vocab=60):
+    words = [bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz ,.") for _ in range(rng.randrange(3, 10))) for _ in range(vocab)]
+    out = bytearray()
+    while len(out) < n:
+        out += rng.choice(words)
+    return bytes(out[:n])
+
+
+def _mixed(rng, n):
+    q = n // 4
+    return _text(rng, q) + bytes([7]) * q + rng.randbytes(q) + _text(rng, n - 3 * q, vocab=400)
+
+
+def _blocks(arc):
+    out, ip = [], 16
+    while arc[ip] != 255:
+        csz = int.from_bytes(arc[ip + 3:ip + 7], "little")
+        out.append((ip, 8 + csz))
+        ip += 8 + csz
+    return out, ip
+
+
+def _as_ref(mockdev):
+    import oracle_py
+    r = oracle_py.Ref.__new__(oracle_py.Ref)
+    r.lib = oracle_py.bind_zxc_api(mockdev)
+    return r
+
+
+@pytest.mark.parametrize("checksum", [False, True])
+def test_push_compress_writes_the_reference_s_archive_in_any_chunking(mockdev, ref, checksum):
+    rng = random.Random(3 + checksum)
+    bs = 4096
+    for n in (0, 1, bs - 1, bs, bs + 1, 20 * bs + 77):
+        data = _mixed(rng, n)
+        want = ref.compress(data, 3, bs, False, checksum)
+        assert api.pstream_compress(data, 8192, 8192, level=3, block_size=bs, checksum=checksum, library=ref.lib) == (0, want)
+        for in_chunk, out_chunk in CHUNKINGS:
+            got = api.pstream_compress(data, in_chunk, out_chunk, level=3, block_size=bs, checksum=checksum, library=mockdev)
+            assert got == (0, want), (n, in_chunk, out_chunk, got[0], len(got[1]), len(want))
+
+
+@pytest.mark.parametrize("seekable", [False, True])
+def test_push_decompress_in_any_chunking(mockdev, ref, seekable):
+    rng = random.Random(5 + seekable)
+    bs = 4096
+    data = _mixed(rng, 20 * bs + 77)
+    for level, checksum in ((3, False), (3, True), (6, True)):
+        arc = ref.compress(data, level, bs, seekable, checksum)
+        for in_chunk, out_chunk in CHUNKINGS:
+            for verify in (False, True):
+                got = api.pstream_decompress(arc, in_chunk, out_chunk, verify, library=mockdev)
+                assert got == (0, data, 1, len(arc)), (level, checksum, in_chunk, out_chunk, verify, got[0], len(got[1]), got[2:])
+
+
+def test_push_streams_across_launch_windows(mockdev, ref):
+    """40 MiB of 4 KiB blocks = 10 240 blocks through windows of 8 192: calls whose input holds more than one launch"""
+    rng = random.Random(7)
+    unit = _mixed(rng, 1 << 20)
+    data = b"".join(unit[i:] + unit[:i] for i in range(0, 40 * 4099, 4099))
+    bs = 4096
+    want = ref.compress(data, 1, bs, False, True)
+    for in_chunk, out_chunk in ((1 << 30, 1 << 30), (36 << 20, 1 << 20), (3 << 20, 38 << 20)):
+        assert api.pstream_compress(data, in_chunk, out_chunk, level=1, block_size=bs, checksum=True, library=mockdev) == (0, want)
+        got = api.pstream_decompress(want, in_chunk, out_chunk, True, library=mockdev)
+        assert got[0] == 0 and got[2:] == (1, len(want)) and got[1] == data, (in_chunk, out_chunk)
+
+
+def test_push_decompress_irregular_frames(mockdev, ref):
+    """a's blocks (the last one short) then b's in one frame: a second launch with capacity-sized slots"""
+    rng = random.Random(23)
+    bs = 4096
+    for k in (1, 5, 40):
+        dA, dB = _text(rng, k * bs + 1000), _text(rng, 30 * bs + 77)
+        a, b = ref.compress(dA, 3, bs, False, False), ref.compress(dB, 3, bs, False, False)
+        A, _ = _blocks(a)
+        B, eofb = _blocks(b)
+        fr = (a[:16] + b"".join(a[o:o + n] for o, n in A) + b"".join(b[o:o + n] for o, n in B) + b[eofb:eofb + 8] +
+              (len(dA) + len(dB)).to_bytes(8, "little") + bytes(4))
+        for in_chunk, out_chunk in ((1 << 20, 1 << 20), (3000, 1 << 20), (1 << 20, 5000), (777, 333)):
+            want = api.pstream_decompress(fr, in_chunk, out_chunk, library=ref.lib)
+            assert want == (0, dA + dB, 1, len(fr))
+            assert api.pstream_decompress(fr, in_chunk, out_chunk, library=mockdev) == want, (k, in_chunk, out_chunk)
+
+
+def test_push_decompress_mutants_get_the_reference_s_verdict(mockdev, ref):
+    """600 mutants, random chunkings: same code, same bytes delivered in front of it, same finished flag; the same input consumed
+    whenever the stream did not fail"""
+    rng = random.Random(2026)
+    bs = 4096
+    data = _mixed(rng, 24 * bs + 99)
+    arcs = [ref.compress(data, lv, bs, sk, ck) for lv, sk, ck in ((3, False, False), (3, True, False), (6, False, True), (1, True, True), (3, False, True))]
+    failed = ok = 0
+    for it in range(600):
+        m = bytearray(rng.choice(arcs))
+        kind = rng.randrange(5)
+        if kind == 0:
+            for _ in range(rng.choice((1, 1, 2, 4))):
+                m[rng.randrange(16, len(m))] ^= 1 << rng.randrange(8)
+        elif kind == 1:
+            p = rng.randrange(16, len(m))
+            m[p:p + rng.randrange(1, 9)] = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 9)))
+        elif kind == 2:
+            m[rng.randrange(16, len(m) - 8)] = rng.choice((0, 0xFF, 0x80, 0x7F, 0xE0))
+        elif kind == 3:
+            cut = rng.randrange(20, len(m))
+            del m[cut:cut + rng.randrange(1, 64)]
+        else:  # a framing byte: a block header's type / size / crc, the EOF block, the footer
+            blocks, eofb = _blocks(arcs[0])
+            m = bytearray(arcs[0])
+            o = rng.choice(blocks)[0] if rng.random() < 0.7 else eofb
+            m[o + rng.randrange(8 if o != eofb else 20)] ^= 1 << rng.randrange(8)
+        m = bytes(m)
+        in_chunk, out_chunk = rng.choice(CHUNKINGS[1:5])
+        verify = rng.random() < 0.5
+        want = api.pstream_decompress(m, in_chunk, out_chunk, verify, library=ref.lib)
+        got = api.pstream_decompress(m, in_chunk, out_chunk, verify, library=mockdev)
+        assert got[:3] == want[:3], (it, kind, in_chunk, out_chunk, verify, got[0], want[0], len(got[1]), len(want[1]))
+        if want[0] == 0:
+            assert got[3] == want[3]
+        failed += want[0] < 0
+        ok += want[0] == 0 and want[2] == 1
+    assert failed >= 200 and ok >= 50, (failed, ok)
+
+
+def test_piece_pipeline_frames_and_ranges(mockdev, ref, monkeypatch):
+    """zxc_compress / zxc_decompress / zxc_seekable_decompress_range through the piece pipeline (1 MiB pieces, two producer threads,
+    the in-order sink) on the mock device: the reference's archive bytes, the source back, the reference's code for a failing block
+    in a later piece"""
+    monkeypatch.setenv("ZXC_MI355X_FRAME_BATCH_MIB", "1")
+    m = _as_ref(mockdev)
+    rng = random.Random(31)
+    bs = 4096
+    data = _mixed(rng, 5 * (1 << 20) + 12345)
+    for seekable, checksum in ((False, False), (True, True)):
+        want = ref.compress(data, 3, bs, seekable, checksum)
+        assert m.compress(data, 3, bs, seekable, checksum) == want
+        rc, got = m.decompress(want, len(data), checksum=checksum)
+        assert rc == len(data) and got == data
+    arc = ref.compress(data, 3, bs, True, False)
+    for _ in range(12):
+        off = rng.randrange(len(data))
+        ln = rng.randrange(1, min(len(data) - off, 2 << 20) + 1)
+        rc, got = m.seekable_range_mt(arc, off, ln, rng.choice((1, 4)))
+        assert rc == ln and got == data[off:off + ln]
+    blocks, _ = _blocks(ref.compress(data, 3, bs, False, False))
+    plain = ref.compress(data, 3, bs, False, False)
+    for bi in (10, 400, 1200):
+        bad = bytearray(plain)
+        o, n = blocks[bi]
+        bad[o + 8 + rng.randrange(12)] ^= 0x40
+        want_rc, _ = ref.decompress(bytes(bad), len(data))
+        rc, _ = m.decompress(bytes(bad), len(data))
+        assert rc == want_rc, (bi, rc, want_rc)

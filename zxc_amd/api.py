@@ -310,6 +310,110 @@ def stream_get_decompressed_size(path, library=None):
         return int(L.zxc_stream_get_decompressed_size(fi))
 
 
+# ---- push streaming (include/zxc_pstream.h). The same prototypes bind the product and (in tests) the reference library.
+class _InBuf(C.Structure):  # zxc_inbuf_t
+    _fields_ = [("src", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+
+class _OutBuf(C.Structure):  # zxc_outbuf_t
+    _fields_ = [("dst", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+
+def _bind_pstream(L):
+    L.zxc_cstream_create.restype = C.c_void_p
+    L.zxc_cstream_create.argtypes = [C.POINTER(_CompressOpts)]
+    L.zxc_cstream_free.argtypes = [C.c_void_p]
+    L.zxc_cstream_compress.restype = C.c_int64
+    L.zxc_cstream_compress.argtypes = [C.c_void_p, C.POINTER(_OutBuf), C.POINTER(_InBuf)]
+    L.zxc_cstream_end.restype = C.c_int64
+    L.zxc_cstream_end.argtypes = [C.c_void_p, C.POINTER(_OutBuf)]
+    L.zxc_dstream_create.restype = C.c_void_p
+    L.zxc_dstream_create.argtypes = [C.POINTER(_DecompressOpts)]
+    L.zxc_dstream_free.argtypes = [C.c_void_p]
+    L.zxc_dstream_decompress.restype = C.c_int64
+    L.zxc_dstream_decompress.argtypes = [C.c_void_p, C.POINTER(_OutBuf), C.POINTER(_InBuf)]
+    L.zxc_dstream_finished.restype = C.c_int
+    L.zxc_dstream_finished.argtypes = [C.c_void_p]
+    for f in ("zxc_cstream_in_size", "zxc_cstream_out_size", "zxc_dstream_in_size", "zxc_dstream_out_size"):
+        getattr(L, f).restype = C.c_size_t
+        getattr(L, f).argtypes = [C.c_void_p]
+    return L
+
+
+def pstream_compress(data: bytes, in_chunk, out_chunk, level=3, block_size=0, checksum=False, library=None):
+    """Feed `data` to a zxc_cstream in chunks of in_chunk bytes, drain through an out buffer of out_chunk bytes, finish with
+    zxc_cstream_end (the loop of the reference's header example, include/zxc_pstream.h:26-49).
+    -> (0, archive) or (negative zxc_error_t, bytes produced so far)."""
+    L = _bind_pstream(library or lib())
+    o = _CompressOpts(level=level, block_size=block_size, checksum_enabled=int(checksum))
+    cs = L.zxc_cstream_create(C.byref(o))
+    if not cs:
+        return None, b""
+    src = C.create_string_buffer(data, max(len(data), 1))
+    base = C.addressof(src)
+    obuf = C.create_string_buffer(max(out_chunk, 1))
+    out = _OutBuf(C.addressof(obuf), out_chunk, 0)
+    blob = bytearray()
+    try:
+        off = 0
+        while off < len(data):
+            n = min(in_chunk, len(data) - off)
+            inb = _InBuf(base + off, n, 0)
+            while inb.pos < inb.size:
+                r = L.zxc_cstream_compress(cs, C.byref(out), C.byref(inb))
+                if r < 0:
+                    return int(r), bytes(blob)
+                if out.pos:
+                    blob += C.string_at(out.dst, out.pos)
+                    out.pos = 0
+                elif r > 0 and out.size == 0:
+                    raise RuntimeError("no progress with an empty out buffer")
+            off += n
+        while True:
+            r = L.zxc_cstream_end(cs, C.byref(out))
+            if r < 0:
+                return int(r), bytes(blob)
+            if out.pos:
+                blob += C.string_at(out.dst, out.pos)
+                out.pos = 0
+            if r == 0:
+                return 0, bytes(blob)
+    finally:
+        L.zxc_cstream_free(cs)
+
+
+def pstream_decompress(comp: bytes, in_chunk, out_chunk, checksum=False, library=None):
+    """Feed `comp` to a zxc_dstream in chunks of in_chunk bytes, drain through an out buffer of out_chunk bytes, until the decoder
+    neither consumes nor produces (reference tests/test_pstream_api.c:107-172).
+    -> (rc of the last call, decoded bytes, finished flag, input bytes consumed)."""
+    L = _bind_pstream(library or lib())
+    o = _DecompressOpts(checksum_enabled=int(checksum))
+    ds = L.zxc_dstream_create(C.byref(o))
+    if not ds:
+        return None, b"", 0, 0
+    src = C.create_string_buffer(comp, max(len(comp), 1))
+    base = C.addressof(src)
+    obuf = C.create_string_buffer(max(out_chunk, 1))
+    out = _OutBuf(C.addressof(obuf), out_chunk, 0)
+    dec = bytearray()
+    try:
+        off = 0
+        while True:
+            n = min(in_chunk, len(comp) - off)
+            inb = _InBuf(base + off if n else None, n, 0)
+            r = L.zxc_dstream_decompress(ds, C.byref(out), C.byref(inb))
+            if out.pos:
+                dec += C.string_at(out.dst, out.pos)
+                out.pos = 0
+            off += inb.pos
+            if r < 0:
+                return int(r), bytes(dec), 0, off
+            if (off >= len(comp) or L.zxc_dstream_finished(ds)) and inb.pos == 0 and r == 0:
+                return 0, bytes(dec), int(L.zxc_dstream_finished(ds)), off
+    finally:
+        L.zxc_dstream_free(ds)
+
+
 def set_debug(lib_handle, flags: int) -> None:
     """tools/ only: the kernel debug switches exist in libraries built with -DZXC_EXPERIMENT (tools/build_variant.sh <name>
     -DZXC_EXPERIMENT, selected with ZXC_LIB_VARIANT); the release library does not export the setter."""

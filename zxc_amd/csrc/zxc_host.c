@@ -1790,3 +1790,4 @@ int64_t zxc_decompress_block_safe(zxc_dctx* dctx, const void* src, const size_t 
 }
 
 #include "zxc_stream_host.inc"
+#include "zxc_pstream_host.c"
