@@ -3,7 +3,7 @@
  * impl src/lib/zxc_pstream.c). The reference composes one zxc_compress_block / one block decode per full block on the calling
  * CPU thread; here a call hands EVERY complete block its input holds to one device launch (one wavefront per block), so the
  * chunk a caller feeds per call is the batch the GPU works on: feed zxc_cstream_in_size() / zxc_dstream_in_size() bytes per
- * call (32 MiB, not one block) for throughput. A block is never held back across calls: when a call returns 0, every block
+ * call (one launch window: 128 MiB, not one block) for throughput. A block is never held back across calls: when a call returns 0, every block
  * completed by its input has been compressed / decoded and drained, like in the reference. Archives are byte for byte what
  * zxc_compress() writes for the same options (non-seekable), whatever the chunking. No CPU codec: without a HIP device the
  * first call that has a block to process returns ZXC_ERROR_GPU_UNAVAILABLE (sticky).

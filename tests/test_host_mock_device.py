@@ -67,8 +67,10 @@ def test_push_decompress_in_any_chunking(mockdev, ref, seekable):
                 assert got == (0, data, 1, len(arc)), (level, checksum, in_chunk, out_chunk, verify, got[0], len(got[1]), got[2:])
 
 
-def test_push_streams_across_launch_windows(mockdev, ref):
-    """40 MiB of 4 KiB blocks = 10 240 blocks through windows of 8 192: calls whose input holds more than one launch"""
+def test_push_streams_across_launch_windows(mockdev, ref, monkeypatch):
+    """40 MiB of 4 KiB blocks = 10 240 blocks through windows of 8 192 (32 MiB instead of the default 128): calls whose input holds
+    more than one launch"""
+    monkeypatch.setenv("ZXC_MI355X_PSTREAM_WINDOW_MIB", "32")
     rng = random.Random(7)
     unit = _mixed(rng, 1 << 20)
     data = b"".join(unit[i:] + unit[:i] for i in range(0, 40 * 4099, 4099))

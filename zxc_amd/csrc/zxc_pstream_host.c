@@ -18,7 +18,17 @@
  * current at its first launch. */
 #include "../../include/zxc_pstream.h"
 
-#define PS_WINDOW_BYTES ((size_t)32 << 20) /* source / decoded bytes of one launch */
+/* source / decoded bytes of one launch: 128 MiB = 2 048 blocks of 64 KiB, one full round of the encoder's workgroups (256 CUs x 8):
+ * a launch takes ~3.5 ms whether it holds 512 blocks or 2 048 (measured, profiles/r5p_pstream_bench.log: 8.5 -> 18 GB/s of source).
+ * A context's device buffers are about four windows on the compression side, two on the decompression side, grown on demand:
+ * a caller that feeds 1 MiB per call never allocates more than that takes. ZXC_MI355X_PSTREAM_WINDOW_MIB = 1 .. 1024 overrides
+ * it when a context is created. */
+static size_t ps_window_bytes(void) {
+    const char* e = getenv("ZXC_MI355X_PSTREAM_WINDOW_MIB");
+    if (e && atoi(e) >= 1 && atoi(e) <= 1024) return (size_t)atoi(e) << 20;
+    return (size_t)128 << 20;
+}
+#define PS_WINDOW_BYTES (ps_window_bytes())
 
 static uint32_t ps_window_blocks(size_t block_size) {
     const size_t n = PS_WINDOW_BYTES / block_size;
@@ -332,6 +342,7 @@ struct zxc_dstream_s {
     uint32_t block_size;   /* 0 until the file header is parsed */
     int file_ck;
     uint32_t max_blocks;
+    size_t window;         /* bytes, fixed at creation */
     uint8_t scratch[32];   /* file header, a block header that straddles calls, the footer */
     size_t scratch_used, scratch_need;
     uint8_t* carry;        /* ONE block frame that straddles calls: header + payload (+ trailer) */
@@ -370,6 +381,7 @@ zxc_dstream* zxc_dstream_create(const zxc_decompress_opts_t* opts) {
     ds->state = DS_FILE_HEADER;
     ds->scratch_need = ZXC_FILE_HEADER_SIZE;
     ds->dev = -1;
+    ds->window = PS_WINDOW_BYTES;
     return ds;
 }
 
@@ -390,10 +402,10 @@ void zxc_dstream_free(zxc_dstream* ds) {
 }
 
 int zxc_dstream_finished(const zxc_dstream* ds) { return (ds && ds->state == DS_DONE) ? 1 : 0; }
-size_t zxc_dstream_in_size(const zxc_dstream* ds) { return ds ? PS_WINDOW_BYTES : 0; }
+size_t zxc_dstream_in_size(const zxc_dstream* ds) { return ds ? ds->window : 0; }
 size_t zxc_dstream_out_size(const zxc_dstream* ds) {
     if (!ds) return 0;
-    return ds->block_size ? (size_t)ds->max_blocks * ds->block_size : PS_WINDOW_BYTES;
+    return ds->block_size ? (size_t)ds->max_blocks * ds->block_size : ds->window;
 }
 
 static int ds_pull_scratch(zxc_dstream* ds, zxc_inbuf_t* in) {
@@ -504,7 +516,7 @@ int64_t zxc_dstream_decompress(zxc_dstream* ds, zxc_outbuf_t* out, zxc_inbuf_t* 
                 if (rc != ZXC_OK) return ds_fail(ds, rc);
                 ds->block_size = bs;
                 ds->file_ck = ck;
-                ds->max_blocks = ps_window_blocks(bs);
+                ds->max_blocks = (uint32_t)(ds->window / bs < 16 ? 16 : ds->window / bs);
                 ds->jobs = (zxc_dev_job_t*)malloc((size_t)ds->max_blocks * sizeof(zxc_dev_job_t));
                 ds->h_st = (int32_t*)malloc((size_t)ds->max_blocks * sizeof(int32_t));
                 if (!ds->jobs || !ds->h_st) return ds_fail(ds, ZXC_ERROR_MEMORY);
