@@ -82,6 +82,18 @@ ZXC_EXPORT void zxc_free_dctx(zxc_dctx* dctx);                         /* :468 *
 ZXC_EXPORT int64_t zxc_decompress_dctx(zxc_dctx* dctx, const void* src, size_t src_size, void* dst,
                                        size_t dst_capacity, const zxc_decompress_opts_t* opts); /* :486 */
 
+/* ---- static contexts: reference include/zxc_buffer.h:494-604 (impl src/lib/zxc_dispatch.c:1860-1965). The context lives in a
+ * buffer the caller owns; zxc_free_* are no-ops on it. The reference carves its tables out of that buffer; here they are in LDS /
+ * device memory, the workspace holds the handle (one cache line, two when carved for levels 6-7). Same contract: block_size
+ * locked (another one: ZXC_ERROR_BAD_BLOCK_SIZE), a raise into levels 6-7 on a workspace carved below them: ZXC_ERROR_BAD_LEVEL,
+ * level / checksum otherwise per call. */
+ZXC_EXPORT size_t zxc_static_cctx_workspace_size(const size_t block_size, const int level); /* :540  0 on invalid arguments */
+ZXC_EXPORT zxc_cctx* zxc_init_static_cctx(void* workspace, const size_t workspace_size,
+                                          const zxc_compress_opts_t* opts);                  /* :567  NULL: too small / invalid */
+ZXC_EXPORT size_t zxc_static_dctx_workspace_size(const size_t block_size);                   /* :581 */
+ZXC_EXPORT zxc_dctx* zxc_init_static_dctx(void* workspace, const size_t workspace_size,
+                                          const size_t block_size);                          /* :601 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,6 @@
 /* subset_main.c — runs the reference's own unit-test functions (compiled in place from /root/reference/tests/*.c, see the
  * Makefile) against libzxc_mi355x.so. Test infrastructure. The case list is the public-API part of the reference's table
- * (tests/test_main.c:60-64 Block API, :50-58 Buffer API, :66-69 contexts, :144-172 seekable, :90-104 push streaming); each function returns 1 on
+ * (tests/test_main.c:60-64 Block API, :50-58 Buffer API, :66-69 contexts, :144-172 seekable, :90-104 push streaming, :72-77 static contexts); each function returns 1 on
  * success like there. Usage: zxc_unit_subset [--list] [name-substring]. Prints "RESULT name PASS|FAIL" per case. */
 #include <stdio.h>
 #include <string.h>
@@ -32,6 +32,9 @@ static const test_entry_t g_tests[] = {
     TEST_CASE(test_pstream_decompress_compatible_with_buffer_api), TEST_CASE(test_pstream_invalid_args),
     TEST_CASE(test_pstream_truncated_input), TEST_CASE(test_pstream_corrupted_magic), TEST_CASE(test_pstream_decode_seekable_archive),
     TEST_CASE(test_pstream_compress_after_end_rejected), TEST_CASE(test_pstream_compress_drain_block_resume),
+    /* static contexts, tests/test_main.c:72-77 */
+    TEST_CASE(test_static_ctx_size_query), TEST_CASE(test_static_ctx_workspace_too_small), TEST_CASE(test_static_ctx_block_size_locked),
+    TEST_CASE(test_static_ctx_level_raise_rejected), TEST_CASE(test_static_ctx_null_inputs), TEST_CASE(test_static_ctx_roundtrip_all_levels),
 };
 
 int main(int argc, char** argv) {

@@ -1608,8 +1608,10 @@ int64_t zxc_seekable_decompress_range_mt(zxc_seekable* s, void* dst, const size_
  * The contexts only carry the sticky options: the working memory of this library lives on the device
  * (per-device arena above), not in the context. */
 #define BLOCK_FORMAT_OVERHEAD 68u /* ZXC_BLOCK_FORMAT_OVERHEAD, src/lib/zxc_internal.h:427 */
-struct zxc_cctx_s { int level; size_t block_size; int checksum; };
-struct zxc_dctx_s { int unused; };
+/* `in_workspace`: the handle lives in a caller-supplied workspace (Static Context API below): zxc_free_* leave it alone, the
+ * block size is locked; `dense`: carved for levels 6-7 */
+struct zxc_cctx_s { int level; size_t block_size; int checksum; int in_workspace; int dense; };
+struct zxc_dctx_s { int in_workspace; size_t block_size; };
 
 uint32_t zxc_get_dict_id(const void* src, const size_t src_size) {
     if (!src || src_size < ZXC_FILE_HEADER_SIZE) return 0;
@@ -1656,9 +1658,52 @@ zxc_cctx* zxc_create_cctx(const zxc_compress_opts_t* opts) {
     c->checksum = opts ? opts->checksum_enabled : 0;
     return c;
 }
-void zxc_free_cctx(zxc_cctx* cctx) { free(cctx); }
+void zxc_free_cctx(zxc_cctx* cctx) { if (cctx && !cctx->in_workspace) free(cctx); }
 zxc_dctx* zxc_create_dctx(void) { return (zxc_dctx*)calloc(1, sizeof(zxc_dctx)); }
-void zxc_free_dctx(zxc_dctx* dctx) { free(dctx); }
+void zxc_free_dctx(zxc_dctx* dctx) { if (dctx && !dctx->in_workspace) free(dctx); }
+
+/* Static Context API (reference include/zxc_buffer.h:494-604, src/lib/zxc_dispatch.c:1860-1965): the whole context in ONE buffer
+ * the caller owns, so that the library never touches the host allocator for it. The reference carves its hash / chain tables,
+ * sequence buffers and (levels 6-7) the optimal parser's scratch out of that buffer; here those live in LDS and in device memory
+ * (the staging arenas, sized per call), so what the workspace holds is the handle — one cache line — and, for a context carved
+ * at the dense tier, a second line (the reference's sizes grow at level 6 too: callers that size per level keep working). The
+ * contract that matters to callers is the reference's: block_size locked (ZXC_ERROR_BAD_BLOCK_SIZE), a raise into levels 6-7 on
+ * a workspace carved below them refused (ZXC_ERROR_BAD_LEVEL), level / checksum otherwise per call, zxc_free_* no-ops. */
+#define STATIC_LINE 64u
+static int valid_block_size(size_t bs) { return bs >= ZXC_BLOCK_SIZE_MIN && bs <= ZXC_BLOCK_SIZE_MAX && !(bs & (bs - 1)); }
+
+size_t zxc_static_cctx_workspace_size(const size_t block_size, const int level) {
+    if (!valid_block_size(block_size) || level < ZXC_LEVEL_FASTEST || level > ZXC_LEVEL_ULTRA) return 0;
+    return STATIC_LINE * (level >= ZXC_LEVEL_DENSITY ? 2u : 1u);
+}
+
+zxc_cctx* zxc_init_static_cctx(void* workspace, const size_t workspace_size, const zxc_compress_opts_t* opts) {
+    if (!workspace || !opts || ((uintptr_t)workspace & (_Alignof(zxc_cctx) - 1))) return NULL;
+    const int level = opts->level > 0 ? opts->level : ZXC_LEVEL_DEFAULT;
+    const size_t bs = opts->block_size > 0 ? opts->block_size : ZXC_BLOCK_SIZE_DEFAULT;
+    const size_t need = zxc_static_cctx_workspace_size(bs, level);
+    if (need == 0 || workspace_size < need) return NULL;
+    zxc_cctx* c = (zxc_cctx*)workspace;
+    memset(c, 0, sizeof(*c));
+    c->level = level;
+    c->block_size = bs;
+    c->checksum = opts->checksum_enabled;
+    c->in_workspace = 1;
+    c->dense = level >= ZXC_LEVEL_DENSITY;
+    return c;
+}
+
+size_t zxc_static_dctx_workspace_size(const size_t block_size) { return valid_block_size(block_size) ? STATIC_LINE : 0; }
+
+zxc_dctx* zxc_init_static_dctx(void* workspace, const size_t workspace_size, const size_t block_size) {
+    if (!workspace || !valid_block_size(block_size) || workspace_size < STATIC_LINE || ((uintptr_t)workspace & (_Alignof(zxc_dctx) - 1)))
+        return NULL;
+    zxc_dctx* d = (zxc_dctx*)workspace;
+    memset(d, 0, sizeof(*d));
+    d->in_workspace = 1;
+    d->block_size = block_size;
+    return d;
+}
 
 /* zxc_compress with sticky options (src/lib/zxc_dispatch.c:1330-1430) */
 int64_t zxc_compress_cctx(zxc_cctx* cctx, const void* src, const size_t src_size, void* dst, const size_t dst_capacity,
@@ -1673,6 +1718,9 @@ int64_t zxc_compress_cctx(zxc_cctx* cctx, const void* src, const size_t src_size
     if (o.level > ZXC_LEVEL_ULTRA) o.level = ZXC_LEVEL_ULTRA;
     if (o.block_size < ZXC_BLOCK_SIZE_MIN || o.block_size > ZXC_BLOCK_SIZE_MAX || (o.block_size & (o.block_size - 1)))
         return ZXC_ERROR_BAD_BLOCK_SIZE;
+    /* a static context: the block size is locked, the dense tier only if carved for it (src/lib/zxc_dispatch.c:1348-1355) */
+    if (cctx->in_workspace && o.block_size != cctx->block_size) return ZXC_ERROR_BAD_BLOCK_SIZE;
+    if (cctx->in_workspace && o.level >= ZXC_LEVEL_DENSITY && !cctx->dense) return ZXC_ERROR_BAD_LEVEL;
     cctx->level = o.level;
     cctx->block_size = o.block_size;
     cctx->checksum = o.checksum_enabled;
@@ -1682,6 +1730,13 @@ int64_t zxc_compress_cctx(zxc_cctx* cctx, const void* src, const size_t src_size
 int64_t zxc_decompress_dctx(zxc_dctx* dctx, const void* src, const size_t src_size, void* dst, const size_t dst_capacity,
                             const zxc_decompress_opts_t* opts) {
     if (!dctx) return ZXC_ERROR_NULL_INPUT;
+    if (dctx->in_workspace) { /* locked to its block size (src/lib/zxc_dispatch.c:1512-1520) */
+        if (!src || !dst || src_size < ZXC_FILE_HEADER_SIZE) return ZXC_ERROR_NULL_INPUT;
+        uint32_t bs = 0, did = 0;
+        int ck = 0;
+        if (read_file_header((const uint8_t*)src, src_size, &bs, &ck, &did) != ZXC_OK) return ZXC_ERROR_BAD_HEADER;
+        if (bs != dctx->block_size) return ZXC_ERROR_BAD_BLOCK_SIZE;
+    }
     return zxc_decompress(src, src_size, dst, dst_capacity, opts);
 }
 
@@ -1699,6 +1754,11 @@ int64_t zxc_compress_block(zxc_cctx* cctx, const void* src, const size_t src_siz
     const size_t min_bs = block_size_ceil(src_size);
     const size_t bs = want_bs > min_bs ? want_bs : min_bs; /* one block: block_size >= src_size */
     if (bs > ZXC_BLOCK_SIZE_MAX || (bs & (bs - 1))) return ZXC_ERROR_BAD_BLOCK_SIZE;
+    if (cctx->in_workspace) { /* src/lib/zxc_dispatch.c:1653-1661 */
+        const size_t eff = b_dict_size ? block_size_ceil(b_dict_size + bs) : bs;
+        if (eff != cctx->block_size) return ZXC_ERROR_BAD_BLOCK_SIZE;
+        if (level >= ZXC_LEVEL_DENSITY && !cctx->dense) return ZXC_ERROR_BAD_LEVEL;
+    }
     cctx->level = level;
     cctx->block_size = bs;
     cctx->checksum = checksum_enabled;
