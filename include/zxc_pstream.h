@@ -1,14 +1,13 @@
 /* zxc_pstream.h — push streaming: the caller feeds input chunks and drains output chunks, nothing blocks on a FILE*.
  * Same names, signatures, return conventions and state-machine behaviour as the reference (include/zxc_pstream.h:82-292,
  * impl src/lib/zxc_pstream.c). The reference composes one zxc_compress_block / one block decode per full block on the calling
- * CPU thread; here a call hands EVERY complete block its input holds to one device launch (one wavefront per block), so the
- * chunk a caller feeds per call is the batch the GPU works on: feed zxc_cstream_in_size() / zxc_dstream_in_size() bytes per
- * call (one launch window: 128 MiB, not one block) for throughput. A block is never held back across calls: when a call returns 0, every block
- * completed by its input has been compressed / decoded and drained, like in the reference. Archives are byte for byte what
- * zxc_compress() writes for the same options (non-seekable), whatever the chunking. No CPU codec: without a HIP device the
- * first call that has a block to process returns ZXC_ERROR_GPU_UNAVAILABLE (sticky).
- * One context, one thread at a time; the context owns device staging buffers on the device that was current at its first
- * launch (grown to the largest batch seen, at most one window) and frees them in *_free. */
+ * CPU thread; here a call hands EVERY complete block its input holds to the device (one wavefront per block, pieces of blocks
+ * pipelined over the library's staging arenas), so the chunk a caller feeds per call is the batch the GPU works on: feed
+ * zxc_cstream_in_size() / zxc_dstream_in_size() bytes (128 MiB, not one block) or more per call for throughput. A block is never
+ * held back across calls: when a call returns 0, every block completed by its input has been compressed / decoded and drained,
+ * like in the reference. Archives are byte for byte what zxc_compress() writes for the same options (non-seekable), whatever
+ * the chunking. No CPU codec: without a HIP device the first call that has a block to process returns
+ * ZXC_ERROR_GPU_UNAVAILABLE (sticky). One context, one thread at a time; the work runs on the calling thread's current device. */
 #ifndef ZXC_PSTREAM_H
 #define ZXC_PSTREAM_H
 #include <stddef.h>

@@ -168,3 +168,39 @@ def test_piece_pipeline_frames_and_ranges(mockdev, ref, monkeypatch):
         want_rc, _ = ref.decompress(bytes(bad), len(data))
         rc, _ = m.decompress(bytes(bad), len(data))
         assert rc == want_rc, (bi, rc, want_rc)
+
+
+def test_push_decompress_many_pieces_irregular_and_failing_blocks(mockdev, ref, monkeypatch):
+    """1 MiB pieces (256 blocks of 4 KiB): a short block in the first piece / in a later one / at a piece border, and a failing
+    block in a later piece, with whole-input calls (everything lands in out) and with windows staged through a small out"""
+    monkeypatch.setenv("ZXC_MI355X_FRAME_BATCH_MIB", "1")
+    monkeypatch.setenv("ZXC_MI355X_PSTREAM_WINDOW_MIB", "2")
+    rng = random.Random(41)
+    bs = 4096
+    for k in (5, 300, 511):
+        dA, dB = _text(rng, k * bs + 1000), _text(rng, 600 * bs + 77)
+        a, b = ref.compress(dA, 3, bs, False, False), ref.compress(dB, 3, bs, False, False)
+        A, _ = _blocks(a)
+        B, eofb = _blocks(b)
+        fr = (a[:16] + b"".join(a[o:o + n] for o, n in A) + b"".join(b[o:o + n] for o, n in B) + b[eofb:eofb + 8] +
+              (len(dA) + len(dB)).to_bytes(8, "little") + bytes(4))
+        for in_chunk, out_chunk in ((1 << 30, 1 << 30), (1 << 30, 100000), (700001, 1 << 30), (300000, 50000)):
+            assert api.pstream_decompress(fr, in_chunk, out_chunk, library=mockdev) == (0, dA + dB, 1, len(fr)), (k, in_chunk, out_chunk)
+    data = _text(rng, 1500 * bs)
+    arc = ref.compress(data, 3, bs, False, True)
+    blocks = []
+    ip = 16
+    while arc[ip] != 255:
+        csz = int.from_bytes(arc[ip + 3:ip + 7], "little")
+        blocks.append((ip, 8 + csz + 4))
+        ip += 8 + csz + 4
+    for bi in ((3,), (700,), (1499,), (300, 900)):
+        bad = bytearray(arc)
+        for x in bi:
+            o, n = blocks[x]
+            bad[o + 8 + rng.randrange(n - 12)] ^= 0x10
+        for in_chunk, out_chunk in ((1 << 30, 1 << 30), (1 << 30, 100000), (300000, 1 << 30)):
+            for verify in (False, True):
+                want = api.pstream_decompress(bytes(bad), in_chunk, out_chunk, verify, library=ref.lib)
+                got = api.pstream_decompress(bytes(bad), in_chunk, out_chunk, verify, library=mockdev)
+                assert got[:3] == want[:3], (bi, in_chunk, out_chunk, verify, got[0], want[0], len(got[1]), len(want[1]))

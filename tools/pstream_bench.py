@@ -61,7 +61,7 @@ def main():
         L.zxc_dstream_free(ds)
         return dt, out.pos
 
-    print(f"{total >> 20} MiB of text, level 3, 64 KiB blocks, window {os.environ.get('ZXC_MI355X_PSTREAM_WINDOW_MIB', '32')} MiB")
+    print(f"{total >> 20} MiB of text, level 3, 64 KiB blocks, window {os.environ.get('ZXC_MI355X_PSTREAM_WINDOW_MIB', '128')} MiB")
     for ch in chunks:
         best_c = best_d = 1e9
         for _ in range(3):

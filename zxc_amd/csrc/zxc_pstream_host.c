@@ -5,24 +5,25 @@
  * Reference: include/zxc_pstream.h:82-292, src/lib/zxc_pstream.c (cstream states :69-79, zxc_cstream_compress :446-508,
  * zxc_cstream_end :525-591; dstream states :634-647, zxc_dstream_decompress :1046-1176). Same entry points, return values and
  * error codes; the difference is the unit of work. The reference calls its block codec once per full block on the calling
- * thread. Here one call hands EVERY block its input completes to one launch:
+ * thread. Here one call hands EVERY block its input completes to the device, through the piece pipeline of zxc_host.c (pieces of
+ * blocks on the streams of the staging arenas: upload of piece i+1 beside the launch of piece i beside the download of piece
+ * i-1; a batch of one piece runs in series on the calling thread):
  *   compress:  [accumulator block (when the previous calls left a partial one and this input fills it)] + all whole blocks of
- *              the caller's input, uploaded side by side, encoded, compacted on the device (offsets kernel + gather) and copied
- *              back — straight into the caller's out when it has the room, else into the pending buffer that later calls drain;
- *   decompress: the block frames that lie whole inside the caller's input are uploaded as ONE span from where they are (no
- *              staging copy), in front of them the one frame that straddled the previous call (the carry buffer); one launch,
- *              statuses checked in stream order (first failing block wins, what precedes it is still delivered), output copied
- *              straight into out when it fits, else staged and drained.
- * A batch never outlives the call that collected it, so "the call returned 0" means what it means in the reference. The device
- * buffers belong to the context (grown to the largest batch seen, at most PS_WINDOW_BYTES of blocks) on the device that was
- * current at its first launch. */
+ *              the caller's input, uploaded from where they are, encoded, compacted on the device and copied back — straight
+ *              into the caller's out when it has the room, else into the pending buffer that later calls drain;
+ *   decompress: the block frames that lie whole inside the caller's input are uploaded from where they are (no staging copy),
+ *              in front of them the one frame that straddled the previous call (the carry buffer); statuses checked in stream
+ *              order (first failing block wins, what precedes it is still delivered), output copied straight into out when it
+ *              fits, else staged and drained.
+ * A batch never outlives the call that collected it, so "the call returned 0" means what it means in the reference. A context
+ * owns no device memory: the pieces run in the library's staging arenas. */
 #include "../../include/zxc_pstream.h"
 
-/* source / decoded bytes of one launch: 128 MiB = 2 048 blocks of 64 KiB, one full round of the encoder's workgroups (256 CUs x 8):
- * a launch takes ~3.5 ms whether it holds 512 blocks or 2 048 (measured, profiles/r5p_pstream_bench.log: 8.5 -> 18 GB/s of source).
- * A context's device buffers are about four windows on the compression side, two on the decompression side, grown on demand:
- * a caller that feeds 1 MiB per call never allocates more than that takes. ZXC_MI355X_PSTREAM_WINDOW_MIB = 1 .. 1024 overrides
- * it when a context is created. */
+/* The window: how much of a call's input becomes one batch when the output cannot go straight into the caller's out (what the
+ * pending / staging buffer of a context can grow to), and the chunk size the *_in_size() calls suggest: 128 MiB = 2 048 blocks of
+ * 64 KiB, one full round of the encoder's workgroups (256 CUs x 8; 32 MiB per call: 8.5 GB/s of source, 128 MiB: 18 GB/s in
+ * series, profiles/r5p_pstream_bench.log). A call whose out has room for everything batches ALL its input.
+ * ZXC_MI355X_PSTREAM_WINDOW_MIB = 1 .. 1024 overrides it when a context is created. */
 static size_t ps_window_bytes(void) {
     const char* e = getenv("ZXC_MI355X_PSTREAM_WINDOW_MIB");
     if (e && atoi(e) >= 1 && atoi(e) <= 1024) return (size_t)atoi(e) << 20;
@@ -34,14 +35,6 @@ static uint32_t ps_window_blocks(size_t block_size) {
     const size_t n = PS_WINDOW_BYTES / block_size;
     return (uint32_t)(n < 16 ? 16 : n);
 }
-static void* ps_dev_reserve(dbuf_t* d, size_t need) {
-    if (d->cap < need) {
-        zxc_mi355x_free(d->p);
-        d->p = zxc_mi355x_malloc(need);
-        d->cap = d->p ? need : 0;
-    }
-    return d->p;
-}
 static int ps_host_reserve(uint8_t** p, size_t* cap, size_t need, int keep) {
     if (*cap >= need) return ZXC_OK;
     uint8_t* nb = keep ? (uint8_t*)realloc(*p, need) : (free(*p), (uint8_t*)malloc(need));
@@ -50,38 +43,20 @@ static int ps_host_reserve(uint8_t** p, size_t* cap, size_t need, int keep) {
     *cap = need;
     return ZXC_OK;
 }
-/* the context's device: the one current at its first launch; a caller that moved on to another device is switched for the
- * duration of the batch */
-static int ps_enter_device(int* ctx_dev, int* prev) {
-    if (zxc_mi355x_device_count() <= 0) return ZXC_ERROR_GPU_UNAVAILABLE;
-    const int cur = zxc_hip_current_device();
-    if (cur < 0) return ZXC_ERROR_GPU_UNAVAILABLE;
-    *prev = cur;
-    if (*ctx_dev < 0) *ctx_dev = cur;
-    return cur == *ctx_dev ? ZXC_OK : zxc_mi355x_set_device(*ctx_dev);
-}
-static void ps_leave_device(int ctx_dev, int prev) {
-    if (prev >= 0 && prev != ctx_dev) (void)zxc_mi355x_set_device(prev);
-}
-
 /* ============================================================ compression */
 enum { CS_INIT = 0, CS_DRAIN_HEADER, CS_ACCUMULATE, CS_DRAIN_BLOCK, CS_DRAIN_LAST, CS_DRAIN_EOF, CS_DRAIN_FOOTER, CS_DONE, CS_ERRORED };
 
 struct zxc_cstream_s {
     int level, checksum;
     size_t block_size;
-    uint32_t max_blocks;  /* blocks per launch */
+    uint32_t max_blocks;  /* blocks of one window */
     uint8_t* in_block;    /* one block: input that does not yet make a whole block */
     size_t in_used;
     uint8_t* pending;     /* output the caller has not drained yet */
     size_t pending_cap, pending_len, pending_pos;
-    uint32_t* h_sizes;
-    size_t h_sizes_cap;   /* entries */
     uint64_t total_in;
     uint32_t global_hash;
     int state, error_code;
-    int dev;
-    dbuf_t d_src, d_slots, d_sizes, d_offs, d_out;
 };
 
 static int cs_fail(zxc_cstream* cs, int code) {
@@ -102,7 +77,6 @@ zxc_cstream* zxc_cstream_create(const zxc_compress_opts_t* opts) {
     cs->checksum = opts ? (opts->checksum_enabled != 0) : 0;
     cs->block_size = bs;
     cs->max_blocks = ps_window_blocks(bs);
-    cs->dev = -1;
     cs->in_block = (uint8_t*)malloc(bs);
     cs->pending_cap = 64;
     cs->pending = (uint8_t*)malloc(cs->pending_cap);
@@ -113,15 +87,6 @@ zxc_cstream* zxc_cstream_create(const zxc_compress_opts_t* opts) {
 
 void zxc_cstream_free(zxc_cstream* cs) {
     if (!cs) return;
-    if (cs->dev >= 0) {
-        int prev = -1;
-        if (ps_enter_device(&cs->dev, &prev) == ZXC_OK) {
-            zxc_mi355x_free(cs->d_src.p); zxc_mi355x_free(cs->d_slots.p); zxc_mi355x_free(cs->d_sizes.p);
-            zxc_mi355x_free(cs->d_offs.p); zxc_mi355x_free(cs->d_out.p);
-        }
-        ps_leave_device(cs->dev, prev);
-    }
-    free(cs->h_sizes);
     free(cs->pending);
     free(cs->in_block);
     free(cs);
@@ -132,66 +97,77 @@ size_t zxc_cstream_out_size(const zxc_cstream* cs) {
     return cs ? (size_t)cs->max_blocks * (size_t)zxc_compress_block_bound(cs->block_size) : 0;
 }
 
-/* One launch over [a[0..alen) | b[0..blen)] (a: the accumulator, one block or the stream's last partial one; b: whole blocks in
- * the caller's input). The blocks' frames land back to back in out (when it has room for all of them) or in pending. */
+/* The blocks of [a[0..alen) | b[0..blen)] (a: the accumulator — one block, or the stream's last partial one; b: whole blocks in the
+ * caller's input) through the encode pipeline of zxc_compress (comp_enqueue / comp_sink above): the accumulator's block is a piece
+ * of its own, the blocks of b follow in pieces. Their frames land back to back in out (when it has room for their bound) or in
+ * pending. */
+typedef struct {
+    const uint8_t *a, *b;
+    size_t alen, blen, block_size;
+    uint32_t next, nb;
+} cs_src_t;
+static int cs_source(void* ctx, uint32_t max_blocks, pipe_piece_t* p) {
+    cs_src_t* c = (cs_src_t*)ctx;
+    const uint32_t f = c->next;
+    if (f >= c->nb) return 0;
+    if (c->alen && f == 0) {
+        p->h_comp = c->a;
+        p->comp_bytes = c->alen;
+        p->n = 1;
+    } else {
+        const uint32_t fb = f - (c->alen ? 1u : 0u), n = c->nb - f < max_blocks ? c->nb - f : max_blocks;
+        const size_t o = (size_t)fb * c->block_size;
+        p->h_comp = c->b + o;
+        p->comp_bytes = c->blen - o < (size_t)n * c->block_size ? c->blen - o : (size_t)n * c->block_size;
+        p->n = n;
+    }
+    p->out_bytes = (size_t)p->n * (c->block_size + 64);
+    p->cookie[0] = f;
+    c->next = f + p->n;
+    return 1;
+}
 static int cs_encode(zxc_cstream* cs, const uint8_t* a, size_t alen, const uint8_t* b, size_t blen, zxc_outbuf_t* out) {
-    const size_t total = alen + blen, bs = cs->block_size;
-    const uint32_t nb = (uint32_t)((total + bs - 1) / bs);
+    const size_t bs = cs->block_size;
+    const uint32_t nb = (alen ? 1u : 0u) + (uint32_t)((blen + bs - 1) / bs);
     if (nb == 0) return ZXC_OK;
-    int prev = -1;
-    int rc = ps_enter_device(&cs->dev, &prev);
-    if (rc != ZXC_OK) return rc;
-    const uint32_t stride = zxc_mi355x_encode_slot_stride((uint32_t)bs);
-    if (cs->h_sizes_cap < nb) {
-        free(cs->h_sizes);
-        cs->h_sizes = (uint32_t*)malloc((size_t)nb * sizeof(uint32_t));
-        cs->h_sizes_cap = cs->h_sizes ? nb : 0;
+    const size_t bound = (size_t)nb * (bs + 80); /* (a block's frame is at most bs + 64: comp_sink) */
+    uint8_t* land;
+    if (out->size - out->pos >= bound) {
+        land = (uint8_t*)out->dst + out->pos;
+    } else {
+        if (ps_host_reserve(&cs->pending, &cs->pending_cap, bound, 0) != ZXC_OK) return ZXC_ERROR_MEMORY;
+        land = cs->pending;
     }
-    uint8_t* d_src = (uint8_t*)ps_dev_reserve(&cs->d_src, total + 64); /* (+64: the match finder's 16-byte compares, zxc_mi355x.h) */
-    void* d_slots = ps_dev_reserve(&cs->d_slots, (size_t)nb * stride);
-    void* d_sizes = ps_dev_reserve(&cs->d_sizes, (size_t)nb * 4);
-    void* d_offs = ps_dev_reserve(&cs->d_offs, (size_t)nb * 8);
-    void* d_out = ps_dev_reserve(&cs->d_out, (size_t)nb * (bs + 72) + 64);
-    if (!cs->h_sizes || !d_src || !d_slots || !d_sizes || !d_offs || !d_out) rc = ZXC_ERROR_MEMORY;
-    if (rc == ZXC_OK && alen) rc = zxc_mi355x_memcpy_h2d(d_src, a, alen);
-    if (rc == ZXC_OK && blen) rc = zxc_mi355x_memcpy_h2d(d_src + alen, b, blen);
-    if (rc == ZXC_OK) rc = zxc_mi355x_encode_blocks_device(d_src, total, (uint32_t)bs, cs->level, cs->checksum, d_slots, (uint32_t*)d_sizes, NULL);
-    if (rc == ZXC_OK) rc = zxc_hip_block_offsets((uint32_t*)d_sizes, (uint64_t*)d_offs, nb, (uint32_t)bs + 65u, NULL);
-    if (rc == ZXC_OK) rc = zxc_mi355x_gather_blocks_device(d_slots, (uint32_t)bs, (const uint32_t*)d_sizes, (const uint64_t*)d_offs, d_out, nb, NULL);
-    if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(cs->h_sizes, d_sizes, (size_t)nb * 4); /* (waits for the three launches) */
-    size_t csum = 0;
-    for (uint32_t i = 0; rc == ZXC_OK && i < nb; i++) {
-        /* never trusted as a copy length nor as the place of a trailer (comp_sink above) */
-        if (cs->h_sizes[i] > bs + 64 || cs->h_sizes[i] < 8u + (cs->checksum ? 4u : 0u)) rc = ZXC_ERROR_CORRUPT_DATA;
-        csum += cs->h_sizes[i];
-    }
-    uint8_t* land = NULL;
-    if (rc == ZXC_OK) {
-        if (out->size - out->pos >= csum) {
-            land = (uint8_t*)out->dst + out->pos;
-        } else {
-            rc = ps_host_reserve(&cs->pending, &cs->pending_cap, csum, 0);
-            land = cs->pending;
-        }
-    }
-    if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(land, d_out, csum);
-    ps_leave_device(cs->dev, prev);
-    if (rc != ZXC_OK) return rc;
-    if (cs->checksum) { /* the block trailers, folded in stream order (src/lib/zxc_pstream.c:198-203) */
-        size_t o = 0;
-        for (uint32_t i = 0; i < nb; i++) {
-            o += cs->h_sizes[i];
-            cs->global_hash = ((cs->global_hash << 1) | (cs->global_hash >> 31)) ^ rd32(land + o - 4);
-        }
-    }
+    size_t piece_bytes = COMP_PIECE_BYTES;
+    { const char* e = getenv("ZXC_MI355X_FRAME_BATCH_MIB"); if (e && atoi(e) >= 1 && atoi(e) <= 1024) piece_bytes = (size_t)atoi(e) << 20; }
+    const uint32_t piece_blocks = (uint32_t)(piece_bytes / bs > 16 ? piece_bytes / bs : 16);
+    cs_src_t src = {a, b, alen, blen, bs, 0, nb};
+    comp_enq_t ce = {cs->level, cs->checksum};
+    comp_sink_t ck;
+    memset(&ck, 0, sizeof ck);
+    ck.dst = land;
+    ck.dst_capacity = bound;
+    ck.block_size = bs;
+    ck.global_hash = cs->global_hash;
+    ck.checksum = cs->checksum;
+    ck.sizes = (uint32_t*)malloc((size_t)nb * sizeof(uint32_t));
+    ck.offs = (uint64_t*)malloc((size_t)piece_blocks * sizeof(uint64_t));
+    int rc = (ck.sizes && ck.offs) ? 0 : ZXC_ERROR_MEMORY;
+    if (rc == 0)
+        rc = pipe_run_ex(cs_source, &src, comp_sink, &ck, comp_enqueue, &ce, (uint32_t)bs, 0, NULL, alen + blen, (uint64_t)nb * bs,
+                         (size_t)piece_blocks * bs, (size_t)16 << 20, 0, PIPE_SLOTS);
+    free(ck.sizes);
+    free(ck.offs);
+    if (rc != 0) return rc < 0 ? rc : ZXC_ERROR_CORRUPT_DATA;
+    cs->global_hash = ck.global_hash; /* (the block trailers, folded in stream order: src/lib/zxc_pstream.c:198-203) */
     if (land == cs->pending) {
-        cs->pending_len = csum;
+        cs->pending_len = ck.op;
         cs->pending_pos = 0;
     } else {
-        out->pos += csum;
+        out->pos += ck.op;
         cs->pending_len = cs->pending_pos = 0;
     }
-    cs->total_in += total;
+    cs->total_in += alen + blen;
     return ZXC_OK;
 }
 
@@ -275,7 +251,8 @@ int64_t zxc_cstream_compress(zxc_cstream* cs, zxc_outbuf_t* out, zxc_inbuf_t* in
                 /* the accumulator's block (if any) and every whole block behind it go up together */
                 size_t k = avail / bs;
                 const size_t kmax = cs->max_blocks - (alen ? 1u : 0u);
-                if (k > kmax) k = kmax;
+                /* everything at once when the frames can land in the caller's out; else a window at a time (pending stays bounded) */
+                if (k > kmax && out->size - out->pos < (k + 1) * (bs + 80)) k = kmax;
                 const int rc = cs_encode(cs, cs->in_block, alen, ip, k * bs, out);
                 if (rc != ZXC_OK) return cs_fail(cs, rc);
                 cs->in_used = 0;
@@ -341,15 +318,16 @@ struct zxc_dstream_s {
     int want_verify;       /* opts.checksum_enabled */
     uint32_t block_size;   /* 0 until the file header is parsed */
     int file_ck;
-    uint32_t max_blocks;
+    uint32_t max_blocks;   /* blocks of one window */
     size_t window;         /* bytes, fixed at creation */
     uint8_t scratch[32];   /* file header, a block header that straddles calls, the footer */
     size_t scratch_used, scratch_need;
     uint8_t* carry;        /* ONE block frame that straddles calls: header + payload (+ trailer) */
     size_t carry_cap, carry_used, carry_need;
-    /* the batch being collected: [carry frame] + frames of the span [span, span + span_len) of the caller's input */
+    /* the batch being collected: [carry frame] + frames of the span [span, span + span_len) of the caller's input; a job's
+     * comp_off is its place in that layout (the carry frame at 0, the span behind it at carry_area) */
     zxc_dev_job_t* jobs;
-    uint32_t n;
+    uint32_t n, jobs_cap;
     int has_carry;
     const uint8_t* span;
     size_t span_len;
@@ -362,9 +340,6 @@ struct zxc_dstream_s {
     uint64_t total_out;
     uint32_t global_hash;
     int state, error_code;
-    int32_t* h_st;
-    int dev;
-    dbuf_t d_comp, d_jobs, d_out, d_status;
 };
 
 static int ds_fail(zxc_dstream* ds, int code) {
@@ -380,21 +355,12 @@ zxc_dstream* zxc_dstream_create(const zxc_decompress_opts_t* opts) {
     ds->want_verify = opts ? (opts->checksum_enabled != 0) : 0;
     ds->state = DS_FILE_HEADER;
     ds->scratch_need = ZXC_FILE_HEADER_SIZE;
-    ds->dev = -1;
     ds->window = PS_WINDOW_BYTES;
     return ds;
 }
 
 void zxc_dstream_free(zxc_dstream* ds) {
     if (!ds) return;
-    if (ds->dev >= 0) {
-        int prev = -1;
-        if (ps_enter_device(&ds->dev, &prev) == ZXC_OK) {
-            zxc_mi355x_free(ds->d_comp.p); zxc_mi355x_free(ds->d_jobs.p); zxc_mi355x_free(ds->d_out.p); zxc_mi355x_free(ds->d_status.p);
-        }
-        ps_leave_device(ds->dev, prev);
-    }
-    free(ds->h_st);
     free(ds->jobs);
     free(ds->decoded);
     free(ds->carry);
@@ -419,79 +385,150 @@ static int ds_pull_scratch(zxc_dstream* ds, zxc_inbuf_t* in) {
     return ds->scratch_used == ds->scratch_need;
 }
 
-/* The launch over the collected batch. Blocks sit back to back in d_out (block i at i * block_size); a batch whose blocks do not
- * all decode to block_size (legal, never written by an encoder of this format: frames glued together from the Block API) runs a
- * second time with one capacity-sized slot per block. What precedes the first failing block is delivered, then the error. */
+/* The collected batch through the decode pipeline (pipe_run above): the carry frame is a piece of its own, the frames of the span
+ * follow in pieces, each uploaded from the caller's input where it lies; a piece's blocks sit back to back in its output (block j
+ * at j * block_size) and go to `land` in stream order. What precedes the first failing block is delivered, then its code. */
+#define DS_STOP_AT_FAILURE 2 /* a sink verdict like PIPE_IRREGULAR */
+static size_t ds_carry_area(const zxc_dstream* ds) { return ds->has_carry ? ((ds->carry_need + 15u) & ~(size_t)15u) : 0; }
+typedef struct {
+    zxc_dstream* ds;
+    uint32_t next;
+} ds_src_t;
+static int ds_source(void* ctx, uint32_t max_blocks, pipe_piece_t* p) {
+    ds_src_t* c = (ds_src_t*)ctx;
+    const zxc_dstream* ds = c->ds;
+    const uint32_t i0 = c->next, bs = ds->block_size;
+    if (i0 >= ds->n) return 0;
+    uint32_t cnt;
+    if (ds->has_carry && i0 == 0) {
+        cnt = 1;
+        p->h_comp = ds->carry;
+        p->comp_bytes = ds->carry_need;
+        p->jobs[0].comp_off = 0;
+        p->jobs[0].comp_size = ds->jobs[0].comp_size;
+    } else {
+        cnt = ds->n - i0 < max_blocks ? ds->n - i0 : max_blocks;
+        const uint64_t lo = ds->jobs[i0].comp_off, hi = ds->jobs[i0 + cnt - 1].comp_off + ds->jobs[i0 + cnt - 1].comp_size;
+        p->h_comp = ds->span + (size_t)(lo - ds_carry_area(ds));
+        p->comp_bytes = (size_t)(hi - lo);
+        for (uint32_t j = 0; j < cnt; j++) {
+            p->jobs[j].comp_off = ds->jobs[i0 + j].comp_off - lo;
+            p->jobs[j].comp_size = ds->jobs[i0 + j].comp_size;
+        }
+    }
+    for (uint32_t j = 0; j < cnt; j++) {
+        p->jobs[j].out_off = (uint64_t)j * bs;
+        p->jobs[j].out_len = bs;
+    }
+    p->n = cnt;
+    p->out_bytes = (size_t)cnt * bs;
+    p->cookie[0] = i0;
+    c->next = i0 + cnt;
+    return 1;
+}
+typedef struct {
+    zxc_dstream* ds;
+    uint8_t* land;
+    size_t cap, landed;
+    uint32_t done; /* blocks delivered (or found failing) so far, in stream order */
+} ds_sink_t;
+static int ds_sink(void* ctx, const pipe_piece_t* p, const int32_t* st, const dev_bufs_t* b) {
+    ds_sink_t* k = (ds_sink_t*)ctx;
+    zxc_dstream* ds = k->ds;
+    const uint32_t i0 = (uint32_t)p->cookie[0], n = p->n, bs = ds->block_size;
+    uint32_t good = n;
+    for (uint32_t i = 0; i < n; i++)
+        if (st[i] < 0) { good = i; break; }
+    /* back to back in the piece's output only if every block but the last delivered one decodes to block_size (a short block in
+     * the middle is legal, never written by an encoder of this format: the caller takes the piece slot by slot) */
+    size_t bytes = 0;
+    for (uint32_t i = 0; i < good; i++) {
+        if ((uint32_t)st[i] > bs || ((uint32_t)st[i] != bs && i + 1 != good)) { k->done = i0; return PIPE_IRREGULAR; }
+        bytes += (size_t)st[i];
+    }
+    if (bytes > k->cap - k->landed) return ZXC_ERROR_OVERFLOW; /* (cannot happen: cap = n * block_size) */
+    const int rc = zxc_mi355x_memcpy_d2h(k->land + k->landed, b->d_out, bytes);
+    if (rc != ZXC_OK) return rc;
+    k->landed += bytes;
+    k->done = i0 + good;
+    if (good < n) { ds->tail_err = st[good]; return DS_STOP_AT_FAILURE; } /* (wins over an error found behind the batch) */
+    return 0;
+}
+/* blocks [j0, n) one capacity-sized slot each, a window at a time, appended to the staging buffer block by block (in series: this
+ * path exists for correctness) */
+static int ds_flush_slots(zxc_dstream* ds, uint32_t j0) {
+    const uint32_t bs = ds->block_size, slot = (bs + TAIL_PAD + 15u) & ~15u;
+    const uint32_t win = ds->max_blocks;
+    zxc_dev_job_t* jobs = (zxc_dev_job_t*)malloc((size_t)win * sizeof(zxc_dev_job_t));
+    int32_t* st = (int32_t*)malloc((size_t)win * sizeof(int32_t));
+    int rc = (jobs && st) ? ZXC_OK : ZXC_ERROR_MEMORY;
+    const int verify = ds->want_verify && ds->file_ck;
+    while (rc == ZXC_OK && j0 < ds->n && !ds->tail_err) {
+        uint32_t cnt;
+        const uint8_t* h_comp;
+        size_t comp_bytes;
+        if (ds->has_carry && j0 == 0) {
+            cnt = 1;
+            h_comp = ds->carry;
+            comp_bytes = ds->carry_need;
+            jobs[0].comp_off = 0;
+        } else {
+            cnt = ds->n - j0 < win ? ds->n - j0 : win;
+            const uint64_t lo = ds->jobs[j0].comp_off, hi = ds->jobs[j0 + cnt - 1].comp_off + ds->jobs[j0 + cnt - 1].comp_size;
+            h_comp = ds->span + (size_t)(lo - ds_carry_area(ds));
+            comp_bytes = (size_t)(hi - lo);
+            for (uint32_t j = 0; j < cnt; j++) jobs[j].comp_off = ds->jobs[j0 + j].comp_off - lo;
+        }
+        for (uint32_t j = 0; j < cnt; j++) {
+            jobs[j].comp_size = ds->jobs[j0 + j].comp_size;
+            jobs[j].out_off = (uint64_t)j * slot;
+            jobs[j].out_len = slot;
+        }
+        dev_bufs_t b;
+        rc = run_jobs_on(h_comp, comp_bytes, jobs, cnt, (size_t)cnt * slot, bs, 0u, verify, st, &b, NULL, 0, NULL);
+        if (rc != ZXC_OK) break;
+        for (uint32_t j = 0; j < cnt && rc == ZXC_OK; j++) {
+            if (st[j] < 0) { ds->tail_err = st[j]; break; }
+            if ((uint32_t)st[j] > slot) { rc = ZXC_ERROR_CORRUPT_DATA; break; } /* (a status is never trusted as a copy length) */
+            rc = ps_host_reserve(&ds->decoded, &ds->decoded_cap, ds->decoded_size + (size_t)st[j], 1);
+            if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(ds->decoded + ds->decoded_size, (const uint8_t*)b.d_out + (size_t)j * slot, (size_t)st[j]);
+            if (rc == ZXC_OK) ds->decoded_size += (size_t)st[j];
+        }
+        dev_bufs_free(&b);
+        j0 += cnt;
+    }
+    free(jobs);
+    free(st);
+    return rc;
+}
 static int ds_flush(zxc_dstream* ds, zxc_outbuf_t* out, size_t* produced) {
     const uint32_t n = ds->n, bs = ds->block_size;
     ds->decoded_size = ds->decoded_pos = 0;
     if (n == 0) return ZXC_OK;
-    int prev = -1;
-    int rc = ps_enter_device(&ds->dev, &prev);
-    if (rc != ZXC_OK) return rc;
-    const size_t carry_area = ds->has_carry ? ((ds->carry_need + 15u) & ~(size_t)15u) : 0;
-    const uint32_t slot = (bs + TAIL_PAD + 15u) & ~15u;
-    uint8_t* d_comp = (uint8_t*)ps_dev_reserve(&ds->d_comp, carry_area + ds->span_len + 64); /* (+64: the kernel's 16-byte reads) */
-    void* d_jobs = ps_dev_reserve(&ds->d_jobs, (size_t)ds->max_blocks * sizeof(zxc_dev_job_t));
-    void* d_status = ps_dev_reserve(&ds->d_status, (size_t)ds->max_blocks * sizeof(int32_t));
-    uint8_t* d_out = (uint8_t*)ps_dev_reserve(&ds->d_out, (size_t)n * bs + 64);
-    if (!d_comp || !d_jobs || !d_status || !d_out) rc = ZXC_ERROR_MEMORY;
-    if (rc == ZXC_OK && ds->has_carry) rc = zxc_mi355x_memcpy_h2d(d_comp, ds->carry, ds->carry_need);
-    if (rc == ZXC_OK && ds->span_len) rc = zxc_mi355x_memcpy_h2d(d_comp + carry_area, ds->span, ds->span_len);
-    const int verify = ds->want_verify && ds->file_ck;
-    int32_t* st = ds->h_st;
-    uint32_t good = n;
-    size_t bytes = 0;
-    int regular = 1;
-    for (int pass = 0; rc == ZXC_OK && pass < 2; pass++) {
-        for (uint32_t i = 0; i < n; i++) {
-            ds->jobs[i].out_off = (uint64_t)i * (pass ? slot : bs);
-            ds->jobs[i].out_len = pass ? slot : bs;
-        }
-        rc = zxc_mi355x_memcpy_h2d(d_jobs, ds->jobs, (size_t)n * sizeof(zxc_dev_job_t));
-        if (rc == ZXC_OK) rc = zxc_mi355x_decode_blocks_device(d_comp, (const zxc_dev_job_t*)d_jobs, n, d_out, (int32_t*)d_status, bs, verify, NULL);
-        if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(st, d_status, (size_t)n * sizeof(int32_t)); /* (waits for the launch) */
-        if (rc != ZXC_OK || pass) break;
-        good = n;
-        for (uint32_t i = 0; i < n; i++)
-            if (st[i] < 0) { good = i; ds->tail_err = st[i]; break; } /* (wins over an error found behind the batch) */
-        bytes = 0;
-        for (uint32_t i = 0; i < good; i++) {
-            if ((uint32_t)st[i] > bs || ((uint32_t)st[i] != bs && i + 1 != good)) regular = 0;
-            bytes += (size_t)st[i];
-        }
-        if (regular) break;
-        d_out = (uint8_t*)ps_dev_reserve(&ds->d_out, (size_t)n * slot + 64);
-        if (!d_out) rc = ZXC_ERROR_MEMORY;
+    const size_t most = (size_t)n * bs;
+    ds_sink_t k;
+    memset(&k, 0, sizeof k);
+    k.ds = ds;
+    k.cap = most;
+    const int direct = out->size - out->pos >= most;
+    if (direct) k.land = (uint8_t*)out->dst + out->pos; /* straight into the caller's buffer */
+    else {
+        if (ps_host_reserve(&ds->decoded, &ds->decoded_cap, most, 0) != ZXC_OK) return ZXC_ERROR_MEMORY;
+        k.land = ds->decoded;
     }
-    if (rc == ZXC_OK && !regular) { /* block by block out of the slots (a status is never trusted as a copy length) */
-        bytes = 0;
-        for (uint32_t i = 0; i < good && rc == ZXC_OK; i++) {
-            if (st[i] < 0 || (uint32_t)st[i] > slot) { rc = st[i] < 0 ? st[i] : ZXC_ERROR_CORRUPT_DATA; break; }
-            bytes += (size_t)st[i];
-        }
-        if (rc == ZXC_OK) rc = ps_host_reserve(&ds->decoded, &ds->decoded_cap, bytes, 0);
-        size_t o = 0;
-        for (uint32_t i = 0; i < good && rc == ZXC_OK; i++) {
-            rc = zxc_mi355x_memcpy_d2h(ds->decoded + o, d_out + (size_t)i * slot, (size_t)st[i]);
-            o += (size_t)st[i];
-        }
-        if (rc == ZXC_OK) ds->decoded_size = bytes;
-    } else if (rc == ZXC_OK && bytes) {
-        if (out->size - out->pos >= bytes) { /* straight into the caller's buffer */
-            rc = zxc_mi355x_memcpy_d2h((uint8_t*)out->dst + out->pos, d_out, bytes);
-            if (rc == ZXC_OK) {
-                out->pos += bytes;
-                *produced += bytes;
-                ds->total_out += bytes;
-            }
+    ds_src_t src = {ds, 0};
+    int rc = pipe_run(ds_source, &src, ds_sink, &k, bs, ds->want_verify && ds->file_ck, NULL, ds_carry_area(ds) + ds->span_len, most, 0, 0,
+                      PIPE_DECODE_SLOTS);
+    if (rc >= 0) {
+        if (direct) {
+            out->pos += k.landed;
+            *produced += k.landed;
+            ds->total_out += k.landed;
         } else {
-            rc = ps_host_reserve(&ds->decoded, &ds->decoded_cap, bytes, 0);
-            if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(ds->decoded, d_out, bytes);
-            if (rc == ZXC_OK) ds->decoded_size = bytes;
+            ds->decoded_size = k.landed;
         }
+        rc = rc == PIPE_IRREGULAR ? ds_flush_slots(ds, k.done) : ZXC_OK;
     }
-    ps_leave_device(ds->dev, prev);
     ds->n = 0;
     ds->has_carry = 0;
     ds->span = NULL;
@@ -517,9 +554,9 @@ int64_t zxc_dstream_decompress(zxc_dstream* ds, zxc_outbuf_t* out, zxc_inbuf_t* 
                 ds->block_size = bs;
                 ds->file_ck = ck;
                 ds->max_blocks = (uint32_t)(ds->window / bs < 16 ? 16 : ds->window / bs);
-                ds->jobs = (zxc_dev_job_t*)malloc((size_t)ds->max_blocks * sizeof(zxc_dev_job_t));
-                ds->h_st = (int32_t*)malloc((size_t)ds->max_blocks * sizeof(int32_t));
-                if (!ds->jobs || !ds->h_st) return ds_fail(ds, ZXC_ERROR_MEMORY);
+                ds->jobs_cap = 256;
+                ds->jobs = (zxc_dev_job_t*)malloc((size_t)ds->jobs_cap * sizeof(zxc_dev_job_t));
+                if (!ds->jobs) return ds_fail(ds, ZXC_ERROR_MEMORY);
                 ds->state = DS_BLOCK_HEADER;
                 ds->scratch_used = 0;
                 ds->scratch_need = BLK_HDR;
@@ -565,15 +602,25 @@ int64_t zxc_dstream_decompress(zxc_dstream* ds, zxc_outbuf_t* out, zxc_inbuf_t* 
                 }
                 const size_t phys = BLK_HDR + (size_t)need;
                 if (direct && avail >= phys) { /* the frame lies whole in the caller's input: it joins the span where it is */
+                    if (ds->n == ds->jobs_cap) {
+                        zxc_dev_job_t* nj = (zxc_dev_job_t*)realloc(ds->jobs, (size_t)ds->jobs_cap * 2 * sizeof(zxc_dev_job_t));
+                        if (!nj) return ds_fail(ds, ZXC_ERROR_MEMORY);
+                        ds->jobs = nj;
+                        ds->jobs_cap *= 2;
+                    }
                     if (ds->span == NULL) { ds->span = hdr; ds->span_len = 0; }
-                    const size_t carry_area = ds->has_carry ? ((ds->carry_need + 15u) & ~(size_t)15u) : 0;
-                    ds->jobs[ds->n].comp_off = carry_area + ds->span_len;
+                    ds->jobs[ds->n].comp_off = ds_carry_area(ds) + ds->span_len;
                     ds->jobs[ds->n].comp_size = (uint32_t)phys;
                     ds->n++;
                     ds->span_len += phys;
                     in->pos += phys;
                     if (ds->want_verify && ds->file_ck) ds->global_hash = ((ds->global_hash << 1) | (ds->global_hash >> 31)) ^ rd32(hdr + BLK_HDR + csz);
-                    if (ds->n == ds->max_blocks) { ds->next_state = DS_BLOCK_HEADER; ds->state = DS_FLUSH; }
+                    /* a window is a batch — unless the caller's out has room for more: then everything the input holds (what does
+                     * not land in out has to fit the staging buffer) */
+                    if (ds->n >= ds->max_blocks && (uint64_t)(ds->n + 1) * ds->block_size > (uint64_t)(out->size - out->pos)) {
+                        ds->next_state = DS_BLOCK_HEADER;
+                        ds->state = DS_FLUSH;
+                    }
                     break;
                 }
                 if (ds->n > 0) { /* the frame is cut by the end of the input: the collected blocks first, then come back */
