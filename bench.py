@@ -696,6 +696,54 @@ def host_api_run(args, dev):
     assert rc == len(data) and dbuf.raw == data, "zxc_decompress: bytes differ"
     res["zxc_decompress"] = {"value": round(len(data) / dt / 1e9, 2), "unit": "GB/s decoded", "ms": round(dt * 1e3, 1),
                              "checked": "every byte == source"}
+    # the push API (include/zxc_pstream.h; reference src/lib/zxc_pstream.c), fed zxc_cstream_in_size() = 128 MiB per call: every block a
+    # call completes goes through the same piece pipeline; the dstream reads what the cstream wrote, every byte compared
+    PS = zxc_amd.api._bind_pstream(L)
+    IB, OB = zxc_amd.api._InBuf, zxc_amd.api._OutBuf
+    a_data = C.cast(C.c_char_p(data), C.c_void_p).value
+    state = {}
+
+    def push_compress():
+        cs = PS.zxc_cstream_create(C.byref(COpts(level=3, block_size=bs)))
+        chunk = int(PS.zxc_cstream_in_size(cs))
+        out = OB(C.addressof(cbuf), cap, 0)
+        off = 0
+        while off < len(data):
+            n = min(chunk, len(data) - off)
+            inb = IB(a_data + off, n, 0)
+            while inb.pos < inb.size:
+                assert PS.zxc_cstream_compress(cs, C.byref(out), C.byref(inb)) >= 0
+            off += n
+        while True:
+            r = PS.zxc_cstream_end(cs, C.byref(out))
+            assert r >= 0
+            if r == 0:
+                break
+        PS.zxc_cstream_free(cs)
+        state["chunk"] = chunk
+        return out.pos
+
+    def push_decompress():
+        ds = PS.zxc_dstream_create(None)
+        out = OB(C.addressof(dbuf), len(data), 0)
+        chunk = max(1 << 16, state["chunk"] * state["csize"] // len(data))  # compressed bytes of about one window of output
+        off = 0
+        while not PS.zxc_dstream_finished(ds):
+            inb = IB(C.addressof(cbuf) + off, min(chunk, state["csize"] - off), 0)
+            r = PS.zxc_dstream_decompress(ds, C.byref(out), C.byref(inb))
+            assert r >= 0 and (r > 0 or inb.pos > 0 or PS.zxc_dstream_finished(ds)), r
+            off += inb.pos
+        PS.zxc_dstream_free(ds)
+        return out.pos
+    C.memset(dbuf, 0, len(data))
+    state["csize"], dt = best_of(push_compress)
+    res["zxc_cstream"] = {"value": round(len(data) / dt / 1e9, 2), "unit": "GB/s of source", "level": 3, "ms": round(dt * 1e3, 1),
+                          "fed_per_call_mib": state["chunk"] >> 20, "ratio": round(len(data) / state["csize"], 3)}
+    rc, dt = best_of(push_decompress)
+    assert rc == len(data) and dbuf.raw == data, "zxc_dstream: bytes differ"
+    res["zxc_dstream"] = {"value": round(len(data) / dt / 1e9, 2), "unit": "GB/s decoded", "ms": round(dt * 1e3, 1),
+                          "fed_per_call_mib": round(max(1 << 16, state["chunk"] * state["csize"] // len(data)) / 2**20, 1),
+                          "checked": "every byte == source, through the archive zxc_cstream wrote"}
     del cbuf, comp
     if oracle_py.Ref.available():
         t0d = tiles[0]

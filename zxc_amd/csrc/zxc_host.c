@@ -1161,7 +1161,8 @@ int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const 
     size_t batch_bytes = COMP_PIECE_BYTES;
     { const char* e = getenv("ZXC_MI355X_FRAME_BATCH_MIB"); if (e && atoi(e) >= 1 && atoi(e) <= 1024) batch_bytes = (size_t)atoi(e) << 20; }
     const uint32_t batch_blocks = (uint32_t)(batch_bytes / block_size > 16 ? batch_bytes / block_size : 16);
-    if (nb > batch_blocks && !dict_size) { /* two pieces or more: pipelined */
+    if (nb > 0 && !dict_size) { /* through the piece pipeline: pipelined when there is more than one piece, else in series on this thread —
+                                 * in the staging arenas either way (round 4: five hipMalloc + hipFree = ~3 ms per call up to 64 MiB) */
         if (zxc_mi355x_device_count() <= 0) return ZXC_ERROR_GPU_UNAVAILABLE;
         sizes = (uint32_t*)malloc((size_t)nb * sizeof(uint32_t));
         if (!sizes) return ZXC_ERROR_MEMORY;
@@ -1169,7 +1170,7 @@ int64_t zxc_compress(const void* src, const size_t src_size, void* dst_v, const 
         const int rc = compress_pieces((const uint8_t*)src, src_size, block_size, level, checksum_enabled, tail_need, dst, dst_capacity,
                                        &op, sizes, nb, (size_t)batch_blocks * block_size, &global_hash);
         if (rc != ZXC_OK) { free(sizes); return rc; }
-    } else if (nb > 0) {
+    } else if (nb > 0) { /* with a dictionary: one shot */
         if (zxc_mi355x_device_count() <= 0) return ZXC_ERROR_GPU_UNAVAILABLE;
         const uint32_t stride = zxc_mi355x_encode_slot_stride((uint32_t)block_size);
         sizes = (uint32_t*)malloc((size_t)nb * sizeof(uint32_t));
@@ -1763,6 +1764,13 @@ int64_t zxc_compress_block(zxc_cctx* cctx, const void* src, const size_t src_siz
     cctx->block_size = bs;
     cctx->checksum = checksum_enabled;
     if (zxc_mi355x_device_count() <= 0) return ZXC_ERROR_GPU_UNAVAILABLE;
+    if (!b_dict_size) { /* one piece of one block in the staging arena (no allocation on the device per call) */
+        size_t op = 0;
+        uint32_t one_size = 0, unused_hash = 0;
+        const int prc = compress_pieces((const uint8_t*)src, src_size, bs, level, checksum_enabled, 0, (uint8_t*)dst, dst_capacity, &op, &one_size, 1u,
+                                        COMP_PIECE_BYTES, &unused_hash);
+        return prc == ZXC_OK ? (int64_t)op : prc;
+    }
     const uint32_t stride = zxc_mi355x_encode_slot_stride((uint32_t)bs);
     void* d_src = zxc_mi355x_malloc(src_size + 64);
     void* d_slot = zxc_mi355x_malloc(stride);
