@@ -204,3 +204,47 @@ def test_push_decompress_many_pieces_irregular_and_failing_blocks(mockdev, ref, 
                 want = api.pstream_decompress(bytes(bad), in_chunk, out_chunk, verify, library=ref.lib)
                 got = api.pstream_decompress(bytes(bad), in_chunk, out_chunk, verify, library=mockdev)
                 assert got[:3] == want[:3], (bi, in_chunk, out_chunk, verify, got[0], want[0], len(got[1]), len(want[1]))
+
+
+def test_file_stream_engine(mockdev, ref, tmp_path, monkeypatch):
+    """zxc_stream_compress / zxc_stream_decompress (the FILE* callers: reader, batches, in-order writer thread) on the mock device:
+    the archive file is byte for byte the reference's zxc_compress of the same bytes, both FILE* decoders give the source back,
+    and a mutated archive gets the reference FILE* decoder's verdict (an error or the same bytes)."""
+    import hashlib
+    monkeypatch.setenv("ZXC_STREAM_BATCH_BYTES", str(2 << 20))  # 512 KiB of source per launch: several batches
+    rng = random.Random(51)
+    data = _mixed(rng, 3 * (1 << 20) + 4321)
+    src = tmp_path / "in.bin"
+    src.write_bytes(data)
+    arc, back = tmp_path / "a.zxc", tmp_path / "back.bin"
+    for level, bs, seekable, ck in ((1, 65536, False, False), (3, 4096, True, True), (5, 512 * 1024, True, False)):
+        n = api.stream_compress(str(src), str(arc), level=level, block_size=bs, seekable=seekable, checksum=ck, library=mockdev)
+        assert n == arc.stat().st_size
+        assert arc.read_bytes() == ref.compress(data, level, bs, seekable, ck), (level, bs, seekable, ck)
+        for lib_ in (mockdev, ref.lib):
+            assert api.stream_decompress(str(arc), str(back), checksum=ck, library=lib_) == len(data)
+            assert hashlib.sha256(back.read_bytes()).digest() == hashlib.sha256(data).digest()
+        assert api.stream_decompress(str(arc), None, checksum=ck, library=mockdev) == len(data)  # integrity only
+        assert api.stream_get_decompressed_size(str(arc), library=mockdev) == len(data)
+    comp = ref.compress(data, 3, 4096, False, True)
+    bad = tmp_path / "bad.zxc"
+    for _ in range(40):
+        m = bytearray(comp)
+        kind = rng.randrange(3)
+        if kind == 0:
+            m[rng.randrange(16, len(m))] ^= 1 << rng.randrange(8)
+        elif kind == 1:
+            del m[rng.randrange(16, len(m)):]
+        else:
+            p = rng.randrange(16, len(m) - 8)
+            m[p:p + 4] = rng.randbytes(4)
+        bad.write_bytes(bytes(m))
+        want = api.stream_decompress(str(bad), str(tmp_path / "w.bin"), checksum=True, library=ref.lib)
+        got = api.stream_decompress(str(bad), str(back), checksum=True, library=mockdev)
+        assert (got < 0) == (want < 0), (kind, got, want)
+        if want >= 0:
+            assert got == want and back.read_bytes() == (tmp_path / "w.bin").read_bytes()
+    empty = tmp_path / "empty.bin"
+    empty.write_bytes(b"")
+    assert api.stream_compress(str(empty), str(arc), library=mockdev) == arc.stat().st_size == 36
+    assert arc.read_bytes() == ref.compress(b"", 3, 65536, True, False)
