@@ -22,6 +22,18 @@ ZXC_EXPORT int64_t zxc_dict_save(const void* content, size_t content_size, const
 ZXC_EXPORT size_t zxc_dict_save_bound(size_t content_size);
 /* :129 — id stored in a .zxd header (0 if not a .zxd) */
 ZXC_EXPORT uint32_t zxc_dict_get_id(const void* buf, size_t buf_size);
+/* :146 — dictionary content from samples: the byte sequences that cover most of the corpus' k-grams (host arithmetic; the
+ * reference's bytes). Size of the content or a negative zxc_error_t */
+ZXC_EXPORT int64_t zxc_train_dict(const void* const* samples, const size_t* sample_sizes, size_t n_samples, void* dict_buf,
+                                  size_t dict_capacity);
+/* :168 — the shared literal table for a trained dictionary: the samples' 4 KiB slices are compressed against it ON THE DEVICE (one
+ * launch) and the literals the parser leaves are histogrammed; a valid 128-byte table for either library, not the reference's
+ * bytes (another parser leaves other literals) */
+ZXC_EXPORT int zxc_train_dict_huf(const void* const* samples, const size_t* sample_sizes, size_t n_samples, const void* dict,
+                                  size_t dict_size, uint8_t* huf_lengths_out);
+/* :191 — both, serialised as a .zxd */
+ZXC_EXPORT int64_t zxc_dict_train(const void* const* samples, const size_t* sample_sizes, size_t n_samples, void* zxd_buf,
+                                  size_t zxd_capacity);
 /* :204 — the 128-byte table inside a .zxd buffer (NULL if not a .zxd) */
 ZXC_EXPORT const void* zxc_dict_huf(const void* buf, size_t buf_size);
 

@@ -15,7 +15,8 @@
 extern "C" {
 #endif
 
-/* reference include/zxc_stream.h:69 — total compressed bytes written, or a negative zxc_error_t */
+/* reference include/zxc_stream.h:69 — total compressed bytes written (f_out may be NULL: dry run, the size only), or a negative
+ * zxc_error_t */
 ZXC_EXPORT int64_t zxc_stream_compress(FILE* f_in, FILE* f_out, const zxc_compress_opts_t* opts);
 
 /* reference include/zxc_stream.h:83 — total decompressed bytes written (f_out may be NULL: integrity

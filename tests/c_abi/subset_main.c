@@ -1,6 +1,6 @@
 /* subset_main.c — runs the reference's own unit-test functions (compiled in place from /root/reference/tests/*.c, see the
  * Makefile) against libzxc_mi355x.so. Test infrastructure. The case list is the public-API part of the reference's table
- * (tests/test_main.c:60-64 Block API, :50-58 Buffer API, :66-69 contexts, :144-172 seekable, :90-104 push streaming, :72-77 static contexts); each function returns 1 on
+ * (tests/test_main.c:60-64 Block API, :50-58 Buffer API, :66-69 contexts, :144-172 seekable, :90-104 push streaming, :72-77 static contexts, :120-141 dictionaries, the FILE* stream cases); each function returns 1 on
  * success like there. Usage: zxc_unit_subset [--list] [name-substring]. Prints "RESULT name PASS|FAIL" per case. */
 #include <stdio.h>
 #include <string.h>
@@ -35,6 +35,17 @@ static const test_entry_t g_tests[] = {
     /* static contexts, tests/test_main.c:72-77 */
     TEST_CASE(test_static_ctx_size_query), TEST_CASE(test_static_ctx_workspace_too_small), TEST_CASE(test_static_ctx_block_size_locked),
     TEST_CASE(test_static_ctx_level_raise_rejected), TEST_CASE(test_static_ctx_null_inputs), TEST_CASE(test_static_ctx_roundtrip_all_levels),
+    /* dictionaries incl. training, tests/test_main.c:120-141 (its .zxd cases build a table with two internal helpers: huf_helpers.c) */
+    TEST_CASE(test_dict_zxd_roundtrip), TEST_CASE(test_dict_id_deterministic), TEST_CASE(test_dict_get_id_apis), TEST_CASE(test_dict_buffer_roundtrip),
+    TEST_CASE(test_dict_block_roundtrip), TEST_CASE(test_dict_block_safe_roundtrip), TEST_CASE(test_dict_mismatch_error), TEST_CASE(test_dict_required_error),
+    TEST_CASE(test_dict_no_dict_compat), TEST_CASE(test_dict_stream_roundtrip), TEST_CASE(test_dict_large_dict_roundtrip), TEST_CASE(test_dict_safe_loop_backref),
+    TEST_CASE(test_dict_seekable_roundtrip), TEST_CASE(test_dict_train_roundtrip), TEST_CASE(test_dict_train_no_frequent_patterns),
+    TEST_CASE(test_dict_seekable_mt_roundtrip), TEST_CASE(test_dict_stream_dict_id_checks), TEST_CASE(test_dict_seekable_dict_id_checks),
+    TEST_CASE(test_dict_huf_zxd_roundtrip), TEST_CASE(test_dict_huf_table_roundtrip), TEST_CASE(test_dict_huf_degenerate_corpus),
+    /* the FILE* stream API, tests/test_main.c (test_stream_api.c) */
+    TEST_CASE(test_null_output_decompression), TEST_CASE(test_invalid_arguments), TEST_CASE(test_truncated_input), TEST_CASE(test_io_failures),
+    TEST_CASE(test_thread_params), TEST_CASE(test_multithread_roundtrip), TEST_CASE(test_stream_get_decompressed_size_errors),
+    TEST_CASE(test_stream_engine_errors), TEST_CASE(test_roundtrip_offset_mixed),
 };
 
 int main(int argc, char** argv) {

@@ -143,10 +143,31 @@ EXPORT uint64_t zxc_mi355x_encode_dict_work_size(uint64_t src_size, uint32_t blo
     (void)src_size; (void)block_size; (void)dict_size;
     return 16;
 }
+/* with a dictionary (include/zxc_mi355x.h:95-102): the reference's Block API takes the dictionary in its options */
 EXPORT int zxc_mi355x_encode_blocks_dict_device(const void* d_src, uint64_t src_size, uint32_t block_size, int level, int ck, const void* d_dict,
                                                 uint32_t dict_size, void* d_work, void* d_slots, uint32_t* d_sizes, void* stream) {
-    (void)d_src; (void)src_size; (void)block_size; (void)level; (void)ck; (void)d_dict; (void)dict_size; (void)d_work; (void)d_slots; (void)d_sizes; (void)stream;
-    return ZXC_ERROR_GPU_UNAVAILABLE; /* (not mocked) */
+    (void)d_work; (void)stream;
+    if (!ref_load()) return ZXC_ERROR_GPU_UNAVAILABLE;
+    zxc_compress_opts_t o;
+    memset(&o, 0, sizeof o);
+    o.level = level;
+    o.block_size = block_size;
+    o.checksum_enabled = ck;
+    o.dict = d_dict;
+    o.dict_size = dict_size;
+    void* cctx = R.create_cctx(&o);
+    if (!cctx) return ZXC_ERROR_MEMORY;
+    const uint32_t stride = zxc_mi355x_encode_slot_stride(block_size);
+    const uint64_t nb = (src_size + block_size - 1) / block_size;
+    int rc = ZXC_OK;
+    for (uint64_t i = 0; i < nb && rc == ZXC_OK; i++) {
+        const uint64_t o0 = i * block_size, len = src_size - o0 < block_size ? src_size - o0 : block_size;
+        const int64_t r = R.compress_block(cctx, (const uint8_t*)d_src + o0, (size_t)len, (uint8_t*)d_slots + i * stride, stride, &o);
+        if (r < 0) rc = (int)r;
+        else d_sizes[i] = (uint32_t)r;
+    }
+    if (R.free_cctx) R.free_cctx(cctx);
+    return rc;
 }
 int zxc_hip_block_offsets(uint32_t* sizes, uint64_t* offs, uint32_t n, uint32_t max_size, void* stream) {
     (void)stream;

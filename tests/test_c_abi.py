@@ -38,11 +38,11 @@ def test_c_programs_link_against_the_product_library():
         out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
         assert "libzxc_mi355x.so" in out and "libzxc_ref" not in out and "not found" not in out, out
     names = subprocess.run([UNIT, "--list"], capture_output=True, text=True, check=True).stdout.split()
-    assert len(names) >= 64 and "test_block_api" in names and "test_seekable_mt_roundtrip" in names and "test_pstream_tiny_chunks" in names
+    assert len(names) >= 94 and "test_block_api" in names and "test_seekable_mt_roundtrip" in names and "test_pstream_tiny_chunks" in names
 
 
 def test_reference_unit_cases_pass_on_the_mock_device(ref):
-    """The same 64 cases against the product's HOST sources over tests/mock_device (host memory; the two kernels' contracts met by
+    """The same 94 cases against the product's HOST sources over tests/mock_device (host memory; the two kernels' contracts met by
     the reference's Block API): the host logic — framing, batching, contexts, push streams, seekable ranges, error codes —
     without a GPU. The device itself: the two tests below."""
     _built()
@@ -51,7 +51,7 @@ def test_reference_unit_cases_pass_on_the_mock_device(ref):
         pytest.skip("tests/c_abi/_bin/zxc_unit_subset_mock not built (needs /root/reference at build time)")
     r = subprocess.run([mock], capture_output=True, text=True, timeout=900)
     res = dict(re.findall(r"^RESULT (\S+) (PASS|FAIL)$", r.stdout, flags=re.M))
-    assert len(res) >= 64 and all(v == "PASS" for v in res.values()), ({k: v for k, v in res.items() if v != "PASS"}, r.stdout[-3000:])
+    assert len(res) >= 94 and all(v == "PASS" for v in res.values()), ({k: v for k, v in res.items() if v != "PASS"}, r.stdout[-3000:])
 
 
 @pytest.mark.gpu
@@ -68,11 +68,11 @@ def test_reference_conformance_program_passes():
 
 @pytest.mark.gpu
 def test_reference_unit_cases_pass():
-    """The public-API cases of reference tests/test_main.c (Buffer / Block / context / seekable / seekable-MT / push streaming / static contexts), compiled from
+    """The public-API cases of reference tests/test_main.c (Buffer / Block / context / seekable / seekable-MT / push streaming / static contexts / dictionaries incl. training / FILE* streams), compiled from
     the reference's own sources, all pass against this library."""
     _built()
     r = subprocess.run([UNIT], capture_output=True, text=True, timeout=1800)
     res = dict(re.findall(r"^RESULT (\S+) (PASS|FAIL)$", r.stdout, flags=re.M))
-    assert len(res) >= 64, r.stdout[-3000:] + r.stderr[-2000:]
+    assert len(res) >= 94, r.stdout[-3000:] + r.stderr[-2000:]
     bad = {k: v for k, v in res.items() if (v == "FAIL") != (k in KNOWN)}
     assert not bad, (bad, r.stdout[-6000:])

@@ -26,7 +26,7 @@ for _ in range(3):
     t = time.perf_counter(); c = zxc_amd.compress(data, 3, 65536, True); dt = time.perf_counter() - t; best = min(best, dt)
 print(f"zxc_compress host->host level 3: {len(data)/best/1e9:.2f} GB/s source ({best*1e3:.1f} ms), ratio {len(data)/len(c):.3f}")
 # FILE* caller: a 1 GiB archive from tmpfs, decoded into tmpfs and integrity-only (f_out = NULL); the read of batch i+1 overlaps
-# the decode + write of batch i (zxc_stream_host.inc)
+# the decode + write of batch i (zxc_stream_host.c)
 if os.environ.get("HB_STREAM", "1") == "1":
     big = data * 16
     arc = "/dev/shm/zxc_hostbench.zxc"; outp = "/dev/shm/zxc_hostbench.out"

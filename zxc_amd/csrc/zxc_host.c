@@ -1857,5 +1857,6 @@ int64_t zxc_decompress_block_safe(zxc_dctx* dctx, const void* src, const size_t 
     return decompress_one_block(src, src_size, dst, dst_capacity, opts, (uint32_t)dst_capacity);
 }
 
-#include "zxc_stream_host.inc"
+#include "zxc_stream_host.c"
 #include "zxc_pstream_host.c"
+#include "zxc_dict_train_host.c"

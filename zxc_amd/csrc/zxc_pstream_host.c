@@ -1,4 +1,4 @@
-/* zxc_pstream_host.c — push streaming (included at the end of zxc_host.c, like zxc_stream_host.inc; a .c so that
+/* zxc_pstream_host.c — push streaming (included at the end of zxc_host.c, like zxc_stream_host.c; a .c so that
  * bench.kernel_sources_hash(), which covers the device sources *.hip / *.inc / *.h of this directory, stays a property of the
  * kernels).
  *

@@ -1,4 +1,4 @@
-/* zxc_stream_host.inc — FILE* callers of the block path (included at the end of zxc_host.c).
+/* zxc_stream_host.c — FILE* callers of the block path (included at the end of zxc_host.c).
  *
  * Reference: src/lib/zxc_driver.c:627-1030 (zxc_stream_engine_run: reader thread -> ring of
  * per-block jobs -> worker threads -> in-order writer), zxc_stream_compress :1038,
@@ -306,7 +306,7 @@ int64_t zxc_stream_decompress(FILE* f_in, FILE* f_out, const zxc_decompress_opts
 }
 
 int64_t zxc_stream_compress(FILE* f_in, FILE* f_out, const zxc_compress_opts_t* opts) {
-    if (!f_in || !f_out) return ZXC_ERROR_NULL_INPUT;
+    if (!f_in) return ZXC_ERROR_NULL_INPUT; /* (f_out NULL: the reference's dry-run mode — everything but the writes, src/lib/zxc_driver.c:1038) */
     const int checksum_enabled = opts ? opts->checksum_enabled : 0;
     const int seekable = opts ? opts->seekable : 0;
     int level = (opts && opts->level > 0) ? opts->level : ZXC_LEVEL_DEFAULT;
@@ -335,7 +335,7 @@ int64_t zxc_stream_compress(FILE* f_in, FILE* f_out, const zxc_compress_opts_t* 
     const uint16_t crc = hdr_hash16(fh);
     fh[14] = (uint8_t)crc;
     fh[15] = (uint8_t)(crc >> 8);
-    if (fwrite(fh, 1, sizeof fh, f_out) != sizeof fh) return ZXC_ERROR_IO;
+    if (f_out && fwrite(fh, 1, sizeof fh, f_out) != sizeof fh) return ZXC_ERROR_IO;
     int64_t out_total = ZXC_FILE_HEADER_SIZE;
 
     size_t batch = STREAM_BATCH_BYTES / 4; /* source bytes per launch */
@@ -401,7 +401,7 @@ int64_t zxc_stream_compress(FILE* f_in, FILE* f_out, const zxc_compress_opts_t* 
             memcpy(all_sizes + all_n, h_sizes, (size_t)nb * 4);
             all_n += nb;
         }
-        if (fwrite(h_out, 1, (size_t)tot, f_out) != (size_t)tot) { ret = ZXC_ERROR_IO; break; }
+        if (f_out && fwrite(h_out, 1, (size_t)tot, f_out) != (size_t)tot) { ret = ZXC_ERROR_IO; break; }
         out_total += (int64_t)tot;
         src_total += got;
         if (opts && opts->progress_cb) opts->progress_cb(src_total, 0, opts->user_data);
@@ -415,7 +415,7 @@ int64_t zxc_stream_compress(FILE* f_in, FILE* f_out, const zxc_compress_opts_t* 
         memset(eofb, 0, sizeof eofb);
         eofb[0] = BLK_EOF;
         eofb[7] = hdr_hash8(eofb);
-        if (fwrite(eofb, 1, sizeof eofb, f_out) != sizeof eofb) ret = ZXC_ERROR_IO;
+        if (f_out && fwrite(eofb, 1, sizeof eofb, f_out) != sizeof eofb) ret = ZXC_ERROR_IO;
         else out_total += BLK_HDR;
         if (ret == 0 && seekable && all_n > 0) {
             if (all_n > 0x3FFFFFFFu) ret = ZXC_ERROR_OVERFLOW;
@@ -426,7 +426,7 @@ int64_t zxc_stream_compress(FILE* f_in, FILE* f_out, const zxc_compress_opts_t* 
                 else {
                     const int64_t w = zxc_write_seek_table(tbl, tsz, all_sizes, (uint32_t)all_n);
                     if (w < 0) ret = w;
-                    else if (fwrite(tbl, 1, (size_t)w, f_out) != (size_t)w) ret = ZXC_ERROR_IO;
+                    else if (f_out && fwrite(tbl, 1, (size_t)w, f_out) != (size_t)w) ret = ZXC_ERROR_IO;
                     else out_total += w;
                     free(tbl);
                 }
@@ -436,7 +436,7 @@ int64_t zxc_stream_compress(FILE* f_in, FILE* f_out, const zxc_compress_opts_t* 
             uint8_t foot[ZXC_FILE_FOOTER_SIZE];
             wr64(foot, src_total);
             wr32(foot + 8, checksum_enabled ? global_hash : 0);
-            if (fwrite(foot, 1, sizeof foot, f_out) != sizeof foot || fflush(f_out) != 0) ret = ZXC_ERROR_IO;
+            if (f_out && (fwrite(foot, 1, sizeof foot, f_out) != sizeof foot || fflush(f_out) != 0)) ret = ZXC_ERROR_IO;
             else out_total += ZXC_FILE_FOOTER_SIZE;
         }
     }
