@@ -54,6 +54,32 @@ def test_reference_unit_cases_pass_on_the_mock_device(ref):
     assert len(res) >= 94 and all(v == "PASS" for v in res.values()), ({k: v for k, v in res.items() if v != "PASS"}, r.stdout[-3000:])
 
 
+FUZZ = ("roundtrip", "decompress", "seekable", "pstream", "dict")
+
+
+def _run_fuzz(prefix, iters, seed):
+    _built()
+    for name in FUZZ:
+        exe = os.path.join(os.path.dirname(UNIT), prefix + name)
+        if not os.path.exists(exe):
+            pytest.skip(f"{exe} not built (needs /root/reference at build time)")
+        r = subprocess.run([exe, str(iters), str(seed)], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and f"FUZZ OK {iters} inputs" in r.stdout, (name, r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_reference_fuzz_harnesses_on_the_mock_device(ref):
+    """The reference's own libFuzzer harnesses (tests/fuzz_*.c: round trip, decoder robustness, seekable, push streams, dictionaries),
+    asserts on, behind a deterministic input generator (tests/c_abi/fuzz_driver.c: random / skewed / repetitive data and stomped
+    valid archives), against the host sources over the mock device."""
+    _run_fuzz("fuzz_mock_", 600, 11)
+
+
+@pytest.mark.gpu
+def test_reference_fuzz_harnesses_pass():
+    """The same harnesses against the product library on the GPU."""
+    _run_fuzz("fuzz_", 150, 5)
+
+
 @pytest.mark.gpu
 def test_reference_conformance_program_passes():
     """reference conformance/test_conformance.c: every valid vector decodes to its .expected bytes, every invalid vector is
