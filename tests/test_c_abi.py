@@ -77,7 +77,7 @@ def test_reference_fuzz_harnesses_on_the_mock_device(ref):
 @pytest.mark.gpu
 def test_reference_fuzz_harnesses_pass():
     """The same harnesses against the product library on the GPU."""
-    _run_fuzz("fuzz_", 150, 5)
+    _run_fuzz("fuzz_", 500, 5)
 
 
 @pytest.mark.gpu
