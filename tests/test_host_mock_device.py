@@ -248,3 +248,28 @@ def test_file_stream_engine(mockdev, ref, tmp_path, monkeypatch):
     empty.write_bytes(b"")
     assert api.stream_compress(str(empty), str(arc), library=mockdev) == arc.stat().st_size == 36
     assert arc.read_bytes() == ref.compress(b"", 3, 65536, True, False)
+
+
+def test_push_streams_from_four_threads_at_once(mockdev, ref):
+    """one context per thread, all of them through the same staging arenas and pipeline (nobody waits for a second arena while
+    holding one): every thread gets its own bytes"""
+    import threading
+    rng = random.Random(61)
+    bs = 4096
+    datas = [_mixed(rng, (300 + 50 * i) * bs + i) for i in range(4)]
+    wants = [ref.compress(d, 3, bs, False, True) for d in datas]
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                assert api.pstream_compress(datas[i], 1 << 30, 8 << 20, level=3, block_size=bs, checksum=True, library=mockdev) == (0, wants[i])
+                assert api.pstream_decompress(wants[i], 200000, 8 << 20, True, library=mockdev) == (0, datas[i], 1, len(wants[i]))
+        except Exception as e:  # noqa: BLE001
+            errs.append((i, repr(e)[:300]))
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs

@@ -351,6 +351,7 @@ def pstream_compress(data: bytes, in_chunk, out_chunk, level=3, block_size=0, ch
         return None, b""
     src = C.create_string_buffer(data, max(len(data), 1))
     base = C.addressof(src)
+    out_chunk = min(out_chunk, len(data) + len(data) // 8 + (1 << 20))  # (no point in allocating more than the archive can take)
     obuf = C.create_string_buffer(max(out_chunk, 1))
     out = _OutBuf(C.addressof(obuf), out_chunk, 0)
     blob = bytearray()
@@ -393,6 +394,8 @@ def pstream_decompress(comp: bytes, in_chunk, out_chunk, checksum=False, library
         return None, b"", 0, 0
     src = C.create_string_buffer(comp, max(len(comp), 1))
     base = C.addressof(src)
+    hint = int.from_bytes(comp[-12:-4], "little") if len(comp) >= 12 else 0  # the footer's size: a hint only (mutants lie)
+    out_chunk = min(out_chunk, max(hint, 1 << 16) + (4 << 20))
     obuf = C.create_string_buffer(max(out_chunk, 1))
     out = _OutBuf(C.addressof(obuf), out_chunk, 0)
     dec = bytearray()
