@@ -8,6 +8,7 @@
  * _bin/libzxc_mockdev.so. */
 #define _GNU_SOURCE
 #include <dlfcn.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -28,39 +29,45 @@ static struct {
     decompress_block_fn decompress_block;
 } R;
 
+static void ref_load_once(void);
+static pthread_once_t g_ref_once = PTHREAD_ONCE_INIT;
 static int ref_load(void) {
-    if (R.h) return 1;
+    pthread_once(&g_ref_once, ref_load_once);
+    return R.h != NULL;
+}
+static void ref_load_once(void) {
     const char* p = getenv("ZXC_MOCK_REF_SO");
     Dl_info info;
     char path[4096];
-    if (!p && dladdr((void*)ref_load, &info) && info.dli_fname) { /* <repo>/tests/mock_device/_bin/x.so -> <repo>/oracle/_ref/libzxc_ref.so */
+    if (!p && dladdr((void*)ref_load_once, &info) && info.dli_fname) { /* <repo>/tests/mock_device/_bin/x.so -> <repo>/oracle/_ref/libzxc_ref.so */
         snprintf(path, sizeof path, "%s", info.dli_fname);
         char* s = strrchr(path, '/');
         if (s) { *s = 0; snprintf(s, sizeof path - (size_t)(s - path), "/../../../oracle/_ref/libzxc_ref.so"); p = path; }
     }
     void* h = p ? dlopen(p, RTLD_NOW | RTLD_LOCAL) : NULL;
-    if (!h) return 0;
+    if (!h) return;
     R.create_cctx = (create_cctx_fn)dlsym(h, "zxc_create_cctx");
     R.create_dctx = (create_dctx_fn)dlsym(h, "zxc_create_dctx");
     R.free_cctx = (free_ctx_fn)dlsym(h, "zxc_free_cctx");
     R.free_dctx = (free_ctx_fn)dlsym(h, "zxc_free_dctx");
     R.compress_block = (compress_block_fn)dlsym(h, "zxc_compress_block");
     R.decompress_block = (decompress_block_fn)dlsym(h, "zxc_decompress_block");
-    if (!R.create_cctx || !R.create_dctx || !R.compress_block || !R.decompress_block) return 0;
+    if (!R.create_cctx || !R.create_dctx || !R.compress_block || !R.decompress_block) return;
     R.h = h;
-    return 1;
 }
 
 #define EXPORT __attribute__((visibility("default")))
-static int g_count = 1; /* ZXC_MOCK_DEVICES=0: behave like a box without a device */
 static __thread int g_dev = 0;
+static int mock_devices(void) { /* ZXC_MOCK_DEVICES=0: behave like a box without a device */
+    const char* e = getenv("ZXC_MOCK_DEVICES");
+    return e ? atoi(e) : 1;
+}
 
 EXPORT int zxc_mi355x_device_count(void) {
-    const char* e = getenv("ZXC_MOCK_DEVICES");
-    if (e) g_count = atoi(e);
-    return g_count > 0 && ref_load() ? g_count : 0;
+    const int n = mock_devices();
+    return n > 0 && ref_load() ? n : 0;
 }
-EXPORT int zxc_mi355x_set_device(int d) { if (d < 0 || d >= g_count) return ZXC_ERROR_GPU_UNAVAILABLE; g_dev = d; return ZXC_OK; }
+EXPORT int zxc_mi355x_set_device(int d) { if (d < 0 || d >= mock_devices()) return ZXC_ERROR_GPU_UNAVAILABLE; g_dev = d; return ZXC_OK; }
 EXPORT int zxc_mi355x_get_device(void) { return g_dev; }
 int zxc_hip_current_device(void) { return g_dev; }
 EXPORT void* zxc_mi355x_malloc(size_t n) { return malloc(n ? n : 16); }
