@@ -42,3 +42,15 @@ def test_reference_unit_cases(san, kind):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=1500, env=san)
     _clean(r, "unit_" + kind)
     assert "SUMMARY ran 94 failed 0" in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("name", ["roundtrip", "decompress", "seekable", "pstream", "dict"])
+def test_reference_fuzz_harnesses_under_asan(san, name):
+    """the reference's libFuzzer harnesses behind tests/c_abi/fuzz_driver.c (random / skewed / repetitive data, stomped and truncated
+    valid archives): the host's parsers — frame walk, seek table, push-stream state machines, .zxd — must stay in bounds"""
+    exe = os.path.join(BIN, "fuzz_asan_" + name)
+    if not os.path.exists(exe):
+        pytest.skip("needs /root/reference at build time")
+    r = subprocess.run([exe, "1500", "3"], capture_output=True, text=True, timeout=900, env=dict(san, ZXC_MI355X_FRAME_BATCH_MIB=""))
+    _clean(r, "fuzz_asan_" + name)
+    assert "FUZZ OK 1500 inputs" in r.stdout
