@@ -8,6 +8,7 @@ import random
 import pytest
 
 import zxc_amd.api as api
+from conftest import push_random_schedule
 
 pytestmark = pytest.mark.gpu
 
@@ -183,3 +184,18 @@ def test_framing_bytes_of_an_empty_stream_flipped(gpu, ref):
             want = api.pstream_decompress(bytes(bad), chunk, 64, True, library=ref.lib)
             # (input consumed is compared unless a BLOCK failed: behind it this decoder has looked at the rest of its batch)
             assert got[:3] == want[:3] and (got[3] == want[3] or (want[0] < 0 and pos in range(16, 24))), (pos, chunk, got, want)
+
+
+def test_random_call_schedules(gpu, ref):
+    """every call with another in / out size (zero included): the archive is zxc_compress's, the reference reads it, the decoder
+    returns the source from a seekable archive of the reference and leaves the bytes behind the footer alone"""
+    bs = 4096
+    for seed in range(8):
+        rng = random.Random(200 + seed)
+        data = _mixed(rng, rng.randrange(1, 40 * bs))
+        checksum = bool(seed & 1)
+        want = gpu.compress(data, level=3, block_size=bs, seekable=False, checksum=checksum)
+        arc = ref.compress(data, 3, bs, True, checksum)
+        blob, dec, used = push_random_schedule(gpu.lib(), data, arc + b"trailing", random.Random(seed), bs, checksum)
+        assert blob == want and dec == data and used == len(arc), (seed, len(blob), len(want), len(dec), used)
+        assert ref.decompress(blob, len(data), checksum=checksum) == (len(data), data)

@@ -8,6 +8,7 @@ import random
 import pytest
 
 import zxc_amd.api as api
+from conftest import push_random_schedule
 
 CHUNKINGS = ((1 << 30, 1 << 30), (8192, 8192), (13 * 1024, 700), (511, 7000), (137, 53), (1, 4096))
 
@@ -273,3 +274,19 @@ def test_push_streams_from_four_threads_at_once(mockdev, ref):
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+def test_push_streams_under_random_call_schedules(mockdev, ref):
+    """every call with another in / out size (zero included): the archive is still the reference's zxc_compress bytes, the decoder
+    still returns the source, consumes the whole archive and nothing behind it; the reference's own push API under the same schedule
+    agrees"""
+    bs = 4096
+    for seed in range(12):
+        rng = random.Random(100 + seed)
+        data = _mixed(rng, rng.randrange(1, 40 * bs))
+        checksum = bool(seed & 1)
+        want = ref.compress(data, 3, bs, False, checksum)
+        seekable_arc = ref.compress(data, 3, bs, True, checksum)
+        for lib_ in (mockdev, ref.lib):
+            blob, dec, used = push_random_schedule(lib_, data, seekable_arc + b"trailing", random.Random(seed), bs, checksum)
+            assert blob == want and dec == data and used == len(seekable_arc), (seed, lib_ is mockdev, len(blob), len(want), len(dec), used)
