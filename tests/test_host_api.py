@@ -22,6 +22,27 @@ def test_exports_every_declared_symbol(product):
         assert hasattr(L, name), f"include/ declares {name} but libzxc_mi355x.so does not export it"
 
 
+def test_exports_the_whole_public_api_of_the_reference_and_what_its_wrappers_call(product):
+    """every function the reference's public headers export (67) — and with them every C function its five language wrappers
+    (go, rust, python, nodejs, wasm: they bind the C API, push streaming included) call — is exported here under the same name"""
+    ref_inc = "/root/reference/include"
+    if not os.path.isdir(ref_inc):
+        pytest.skip("/root/reference is not here")
+    L = product.lib()
+    public = set()
+    for h in os.listdir(ref_inc):
+        public |= set(re.findall(r"ZXC_EXPORT[^;(]*?\b(zxc_\w+)\s*\(", open(os.path.join(ref_inc, h)).read()))
+    assert len(public) == 67
+    missing = sorted(n for n in public if not hasattr(L, n))
+    assert not missing, missing
+    used = set()
+    for rel in ("python/src/zxc/_zxc.c", "nodejs/src/zxc_addon.cc", "rust/zxc-sys/src/lib.rs", "go/zxc.go", "go/zxc_stream.go", "wasm/zxc_wasm.js"):
+        f = os.path.join("/root/reference/wrappers", rel)
+        if os.path.exists(f):
+            used |= set(re.findall(r"\b_?(zxc_[a-z0-9_]+)\b", open(f, errors="replace").read())) & public
+    assert len(used) >= 30 and all(hasattr(L, n) for n in used)
+
+
 def test_no_oracle_or_reference_linked(product):
     """The product must not link the checkers."""
     import subprocess
