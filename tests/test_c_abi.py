@@ -7,6 +7,7 @@ one. The binaries are built where /root/reference exists (__graft_entry__.build(
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -52,6 +53,20 @@ def test_reference_unit_cases_pass_on_the_mock_device(ref):
     r = subprocess.run([mock], capture_output=True, text=True, timeout=900)
     res = dict(re.findall(r"^RESULT (\S+) (PASS|FAIL)$", r.stdout, flags=re.M))
     assert len(res) >= 94 and all(v == "PASS" for v in res.values()), ({k: v for k, v in res.items() if v != "PASS"}, r.stdout[-3000:])
+
+
+def test_reference_python_wrapper_passes_its_own_tests_on_the_mock_device(ref):
+    """The reference's Python wrapper (its C extension compiled in place from wrappers/python/src/zxc/_zxc.c, its package imported
+    from where it lies) linked against this library's host sources over the mock device: the wrapper's OWN test suite
+    (wrappers/python/tests: buffer, dict, io adapters, push streams, seekable, FILE* streams) passes — a language binding keeps
+    working after the relink."""
+    _built()
+    ext_dir = os.path.join(os.path.dirname(UNIT), "pywrap")
+    if not (os.path.isdir(ext_dir) and os.path.isdir("/root/reference/wrappers/python/tests")):
+        pytest.skip("tests/c_abi/_bin/pywrap not built / the reference's wrapper tests are not here")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "c_abi", "run_ref_pytests.py"), ext_dir], capture_output=True, text=True, timeout=900)
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert r.returncode == 0 and m and int(m.group(1)) >= 80 and "failed" not in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
 
 
 FUZZ = ("roundtrip", "decompress", "seekable", "pstream", "dict")
