@@ -69,6 +69,70 @@ def test_reference_python_wrapper_passes_its_own_tests_on_the_mock_device(ref):
     assert r.returncode == 0 and m and int(m.group(1)) >= 80 and "failed" not in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
 
 
+def _cli_scenario(cli, ref, tmp_path, exact):
+    """compress (seekable, checksums: the tool's defaults), test, list, decompress, pipes, train a dictionary, use it, miss it"""
+    import random
+    rng = random.Random(3)
+    words = [bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randrange(3, 10))) for _ in range(200)]
+    text = b" ".join(rng.choice(words) for _ in range(300000))
+    (tmp_path / "a.txt").write_bytes(text)
+    for i in range(40):
+        (tmp_path / f"s{i}.json").write_bytes(b"".join(b'{"id": %d, "user": "user%d", "status": "active", "tags": ["alpha", "beta"]}\n' % (j, j % 97)
+                                                        for j in range(i * 30, (i + 1) * 30)))
+
+    def run(*args, stdin=None):
+        return subprocess.run([cli, *args], cwd=tmp_path, capture_output=True, timeout=300, input=stdin)
+    r = run("-3", "-S", "a.txt", "-o", "a.zxc")
+    assert r.returncode == 0, r.stderr[-500:]
+    arc = (tmp_path / "a.zxc").read_bytes()
+    assert ref.decompress(arc, len(text), checksum=True) == (len(text), text)
+    if exact:  # (on the mock device the block codec is the reference's: the file is the reference's zxc_compress of the same bytes)
+        assert arc == ref.compress(text, 3, 512 * 1024, True, True)
+    r = run("-t", "a.zxc")
+    assert r.returncode == 0 and b"OK" in r.stdout + r.stderr
+    r = run("-l", "a.zxc")
+    assert r.returncode == 0 and b"a.zxc" in r.stdout + r.stderr
+    assert run("-d", "a.zxc", "-o", "a.out").returncode == 0 and (tmp_path / "a.out").read_bytes() == text
+    z = run("-z", "-N", stdin=text)
+    assert z.returncode == 0 and ref.decompress(z.stdout, len(text)) == (len(text), text)
+    d = run("-d", stdin=z.stdout)
+    assert d.returncode == 0 and d.stdout == text
+    bad = bytearray(arc)
+    bad[len(bad) // 2] ^= 0x20
+    (tmp_path / "bad.zxc").write_bytes(bytes(bad))
+    assert run("-t", "bad.zxc").returncode != 0
+    r = run("--train", *[f"s{i}.json" for i in range(40)], "-o", "d.zxd")
+    assert r.returncode == 0 and (tmp_path / "d.zxd").stat().st_size > 16 + 128, r.stderr[-500:]
+    assert run("-5", "-B", "4K", "-D", "d.zxd", "s1.json", "-o", "s1.zxc").returncode == 0
+    assert run("-5", "-B", "4K", "s1.json", "-o", "s1_plain.zxc").returncode == 0
+    assert (tmp_path / "s1.zxc").stat().st_size < (tmp_path / "s1_plain.zxc").stat().st_size  # (the dictionary pays)
+    assert run("-d", "-D", "d.zxd", "s1.zxc", "-o", "s1.out").returncode == 0
+    assert (tmp_path / "s1.out").read_bytes() == (tmp_path / "s1.json").read_bytes()
+    r = run("-d", "s1.zxc", "-o", "s1.none")
+    assert r.returncode != 0 and b"DICT_REQUIRED" in r.stdout + r.stderr
+
+
+def _cli(name):
+    _built()
+    exe = os.path.join(os.path.dirname(UNIT), name)
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} not built (needs /root/reference at build time)")
+    return exe
+
+
+def test_reference_cli_on_the_mock_device(ref, tmp_path):
+    """The reference's command-line tool (src/cli/main.c, compiled in place, public API only) linked against this library's host
+    sources over the mock device."""
+    _cli_scenario(_cli("zxc_cli_mock"), ref, tmp_path, exact=True)
+
+
+@pytest.mark.gpu
+def test_reference_cli_on_the_device(ref, tmp_path):
+    """The same tool linked against libzxc_mi355x.so: the reference's CLI compresses, tests, lists, decompresses, trains and uses a
+    dictionary on the GPU; the unmodified reference library reads what it wrote."""
+    _cli_scenario(_cli("zxc_cli"), ref, tmp_path, exact=False)
+
+
 FUZZ = ("roundtrip", "decompress", "seekable", "pstream", "dict")
 
 
