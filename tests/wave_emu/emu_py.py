@@ -16,9 +16,11 @@ def build(quiet=True):
 
 
 class Emu:
-    def __init__(self):
+    def __init__(self, variant=None):
+        """variant="own": the build with the output-owner executor in the lean kernel (libzxc_wave_emu_own.so)."""
         build()
-        L = self.lib = C.CDLL(SO)
+        variant = variant or os.environ.get("ZXC_EMU_VARIANT")
+        L = self.lib = C.CDLL(SO.replace(".so", f"_{variant}.so") if variant else SO)
         L.emu_decode_blocks.restype = C.c_int
         L.emu_decode_blocks.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_uint32, C.c_int, C.c_char_p, C.c_uint32, C.c_char_p]

@@ -117,8 +117,12 @@ void lds_write(void* p, const void* data, unsigned size, bool is_or) {
     S.wv[S.cw].wlog[S.cur].push_back(w);
 }
 void lds_read(const void* p, void* out, unsigned size) {
+    if (((uintptr_t)p & (size - 1u)) != 0) { fprintf(stderr, "wave_emu: misaligned %u-byte LDS load\n", size); abort(); }
+    lds_read_unaligned(p, out, size);
+}
+void lds_read_unaligned(const void* p, void* out, unsigned size) {  // (gfx950 runs the LDS in unaligned access mode: any byte address)
     const uintptr_t a = (uintptr_t)p;
-    if ((a & (size - 1u)) != 0) { fprintf(stderr, "wave_emu: misaligned %u-byte LDS load\n", size); abort(); }
+    if (a < (uintptr_t)__start_emu_lds || a + size > (uintptr_t)__stop_emu_lds) { fprintf(stderr, "wave_emu: LDS load outside the LDS\n"); abort(); }
     memcpy(out, p, size);
     uint8_t* o = (uint8_t*)out;
     for (const auto& w : S.wv[S.cw].wlog[S.cur]) {  // the lane's own earlier writes of this interval, in order

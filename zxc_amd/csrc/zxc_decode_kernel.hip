@@ -1232,9 +1232,17 @@ __device__ __forceinline__ void decode_one_block(const uint8_t* __restrict__ com
     // One workgroup (= one wavefront) per block: the hardware dispatcher hands out blocks as
     // wave slots free up, which is all the dynamic scheduling RAW-vs-dense blocks need.
 #if defined(EXP_NO_PIV_LDS) || defined(ZXC_LEAN_KERNEL)  // (experiment: occupancy without the PivCo tables; lean variant: never decodes a section)
+#ifdef LEAN_OWNER
+    __shared__ union { WaveLds w; LeanLds l; } lds;
+#else
     __shared__ union { WaveLds w; } lds;
+#endif
+#else
+#ifdef LEAN_OWNER
+    __shared__ union { WaveLds w; PivLds p; LeanLds l; } lds;  // (the owner executor's queue and window make its LDS the larger one)
 #else
     __shared__ union { WaveLds w; PivLds p; } lds;  // the PivCo tables reuse the ring's LDS (never live together)
+#endif
 #endif
     WaveLds& L = lds.w;
     const int lane = threadIdx.x;
