@@ -61,6 +61,20 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         print(f"  total mean {ph.sum(axis=1).mean():.0f} clk/block over {ph.shape[0]} blocks; batches/block {cnt[:, 0].mean():.1f}, "
               f"rounds/block {cnt[:, 1].mean():.1f}", flush=True)
         sys.exit(0)
+    if os.environ.get("AB_TIMES"):  # library built with -DEXP_TIMES: status = start (hi 16) | duration (lo 16), units of 0.32 us
+        st = d_st.cpu().numpy().view(np.uint32)
+        start = (st >> 16).astype(np.int64); dur = (st & 0xFFFF).astype(np.float64) * 0.32
+        piv = int(np.median(start)); start = (((start - piv + 0x8000) & 0xFFFF) - 0x8000).astype(np.float64) * 0.32
+        start -= start.min(); end = start + dur
+        print(f"blocks {st.size}  kernel span {end.max():.0f} us  mean block {dur.mean():.0f} us  p50 {np.percentile(dur,50):.0f}  p90 {np.percentile(dur,90):.0f}  "
+              f"p99 {np.percentile(dur,99):.0f}  p99.9 {np.percentile(dur,99.9):.0f}  max {dur.max():.0f}")
+        print(f"sum(block time)/span = average residency {dur.sum()/end.max():.0f} blocks ({dur.sum()/end.max()/256:.1f} per CU)")
+        T = end.max(); bins = 20; edges = np.linspace(0, T, bins + 1)
+        res = [(np.minimum(end, edges[i+1]) - np.maximum(start, edges[i])).clip(0).sum() / (edges[i+1]-edges[i]) for i in range(bins)]
+        print("residency per time bin:", " ".join(f"{r:.0f}" for r in res))
+        worst = np.argsort(-dur)[:12]
+        print("slowest blocks (index in corpus tile, us, compressed size):", [(int(i % 3234), int(dur[i]), int(sizes[i])) for i in worst], flush=True)
+        sys.exit(0)
     ok = bool((d_st == 65536).all().item()) and torch.equal(d_out[:n * 65536], d_want)
     best = 1e9
     for _ in range(3):

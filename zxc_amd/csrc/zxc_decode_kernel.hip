@@ -1450,6 +1450,9 @@ __device__ __forceinline__ void lean_one_block(const uint8_t* __restrict__ comp,
     // (cap_override: only ever 0 here. A launch with the strict capacity of zxc_decompress_block_safe — exact checks, none of
     // the reference's 4x-batch reserve — goes to the full kernel alone: zxc_hip_shim.hip. The argument stays for the ABI.)
     const uint32_t cap = cap_override ? cap_override : block_size + 2112u;
+#ifdef EXP_TIMES  // experiment only (tools/blocktimes.py): status = start (hi 16) and duration (lo 16) in units of 32 ticks of the 100 MHz clock
+    const uint64_t t_start = wall_clock64();
+#endif
     const uint64_t comp_off = jobs[b].comp_off;
     const uint32_t src_sz = uni(jobs[b].comp_size);
     const uint32_t out_len = uni(jobs[b].out_len);
@@ -1498,6 +1501,13 @@ __device__ __forceinline__ void lean_one_block(const uint8_t* __restrict__ comp,
             rc = E_BAD_BLOCK_TYPE;
         }
     }
+#ifdef EXP_TIMES
+    __builtin_amdgcn_s_waitcnt(0);
+    {
+        const uint64_t t_end = wall_clock64();
+        rc = (int)((((uint32_t)(t_start >> 5) & 0xFFFFu) << 16) | (uint32_t)(((t_end - t_start) >> 5) & 0xFFFFu));
+    }
+#endif
     if (lane == 0) status[b] = rc == ZXC_DEV_DEFER ? ZXC_DEV_E_INTERNAL : rc;  // (DEFER cannot happen: see classify_block)
 }
 

@@ -16,7 +16,7 @@
     defined(EXP_NO_PRE) || defined(EXP_NT_FAR) || defined(EXP_NT_LIT) || defined(EXP_OPTPARSE_L7) || defined(EXP_PDIR_BADOUT) || \
     defined(EXP_PDIR_STOP1) || defined(EXP_PDIR_STOP2) || defined(EXP_PDIR_STOP3) || defined(EXP_PHASES) || defined(EXP_PIV_NOSTORE) || \
     defined(EXP_PIV_PROF) || defined(EXP_PRIO) || defined(EXP_RLE_FULL) || defined(EXP_SKIP_FULL) || defined(EXP_TIMES) || defined(FAR_EARLY) || \
-    defined(FAR_PRELOAD) || defined(FLUSH_NT) || defined(LDS_FENCE_SCOPE) || defined(LEAN_OWNER) || defined(OWN_Q) || defined(LEAN_WAVES_PER_SIMD) || defined(LEAN_FLUSH_CHUNKS) || defined(LIT_LOOP2) || \
+    defined(FAR_PRELOAD) || defined(FLUSH_NT) || defined(LDS_FENCE_SCOPE) || defined(LEAN_OWNER) || defined(OWN_Q) || defined(OWN_C_STORE) || defined(LEAN_WAVES_PER_SIMD) || defined(LEAN_FLUSH_CHUNKS) || defined(LIT_LOOP2) || \
     defined(LIT_MED) || defined(LIT_PREFETCH) || defined(LIT_PREFETCH_AHEAD) || defined(LIT_PRELOAD) || defined(MATCH_MED) || \
     defined(PIV_FLAT_INFLIGHT) || defined(PIV_INFLIGHT) || defined(PIV_VARIANT_FILE) || defined(REDIRECT_PASSES) || defined(RING_BYTES) || \
     defined(SPARSE_MAX) || defined(TILE_MAX) || defined(WAVES_PER_SIMD) || defined(ZXC_RLE_LEAN_MAX_JOBS)
