@@ -444,3 +444,48 @@ def test_encoder_parse_fuzz_on_emulator(emu, ref, oracle):
         if case % 16 == 0:
             rc, out = ref.decompress(comp, len(data), checksum=bool(case & 8))
             assert rc == len(data) and out == data, ("reference decoder", case, level, n, rc)
+
+
+# ---- round 6: the output-owner executor (zxc_amd/csrc/zxc_seq_own.inc, an A/B build of the lean kernel: -DLEAN_OWNER) stays bit-exact
+@pytest.fixture(scope="module")
+def emu_own():
+    import emu_py
+    return emu_py.Emu("own")
+
+
+def test_owner_executor_conformance_and_synth(emu_own, oracle, manifest):
+    for name in _valid_names():
+        if name.startswith("dict_"):
+            continue  # (dictionary archives run the full kernel's executor)
+        _check_archive(emu_own, oracle, read(f"conformance/valid/{name}.zxc"), verify=True)
+    n = 0
+    for name, meta in manifest["synth"].items():
+        if meta["size"] > 400_000:
+            continue
+        _check_archive(emu_own, oracle, read(f"synth/{name}.zxc"), verify=bool(meta["checksum"]))
+        n += 1
+    assert n >= 12
+
+
+def test_owner_executor_mutated_blocks_match_oracle(emu_own, oracle):
+    """Same status code and bytes as the oracle on bit-flipped blocks: the parse's deferred error return, rows cut short by one."""
+    import emu_py
+    rng = random.Random(11)
+    for name, rounds in (("text_200k_l3_b4k", 3), ("seek_70001_l3_b16k", 4), ("mixed_384k_l1_b64k", 1), ("mixed_384k_l3_b64k", 1)):
+        comp = read(f"synth/{name}.zxc")
+        jobs, bs, ck, total = emu_py.frame_jobs(comp)
+        for _ in range(rounds):
+            m = bytearray(comp)
+            for j in jobs:
+                for _ in range(rng.choice((1, 1, 2, 3))):
+                    m[int(j["comp_off"]) + 8 + rng.randrange(int(j["comp_size"]) - 8)] ^= 1 << rng.randrange(8)
+            m = bytes(m)
+            st, out = emu_own.decode_jobs(m, jobs, total, bs)
+            for i, j in enumerate(jobs):
+                blk = m[int(j["comp_off"]):int(j["comp_off"]) + int(j["comp_size"])]
+                rc, want = oracle.decode_block(blk, bs)
+                assert st[i] == rc, (name, i, st[i], rc)
+                if rc >= 0:
+                    n = min(rc, int(j["out_len"]))
+                    o = int(j["out_off"])
+                    assert out[o:o + n] == want[:n], (name, i)
