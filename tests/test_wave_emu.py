@@ -489,3 +489,15 @@ def test_owner_executor_mutated_blocks_match_oracle(emu_own, oracle):
                     n = min(rc, int(j["out_len"]))
                     o = int(j["out_off"])
                     assert out[o:o + n] == want[:n], (name, i)
+
+
+def test_big_blocks_take_the_wide_chain_ring(emu, ref):
+    """Round 6: above 64 KiB blocks levels 3-5 run the entry with the 2^15-position chain ring (zxc_enc_level_bs): 512 KiB of text in
+    one block comes out within 2 % of the reference's size (the 2^11-position ring of the 64 KiB entry: + 9 %), and round-trips."""
+    from zxc_amd import corpus
+    text = corpus.synth_text(1 << 20, seed=5)[:524288]
+    ours = emu.encode(text, 3, 524288)
+    theirs = ref.compress(text, 3, 524288, True, False)
+    rc, out = ref.decompress(ours, len(text))
+    assert rc == len(text) and out == text
+    assert len(ours) <= 1.02 * len(theirs), (len(ours), len(theirs))

@@ -20,7 +20,8 @@ extern char __start_emu_lds[], __stop_emu_lds[];
 #include "zxc_encode_levels.h"
 static void zxc_encode_dispatch(int level, const uint8_t* src, uint64_t src_size, uint32_t block_size, uint8_t* slots,
                                 uint32_t stride, uint32_t* sizes, uint32_t nb, uint32_t ck, uint32_t dict_size, uint8_t* hs) {
-    const zxc_enc_level_t p = zxc_enc_level(level);
+    zxc_enc_level_t p = zxc_enc_level_bs(level, block_size);
+    if (const char* e = getenv("ZXC_EMU_ENC_ENTRY")) p.entry = atoi(e);  // (design experiments: another table geometry at the level's search effort)
     switch (p.entry) {
         case 0: zxc_encode_blocks_kernel_l1(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size, hs, p.huf); break;
         case 1: zxc_encode_blocks_kernel_l2(src, src_size, block_size, slots, stride, sizes, nb, ck, p.depth, p.sufficient, p.lazy, dict_size, hs, p.huf); break;

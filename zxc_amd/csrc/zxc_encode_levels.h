@@ -20,4 +20,12 @@ static inline zxc_enc_level_t zxc_enc_level(int level) {
     };
     return t[level < 1 ? 1 : (level > 7 ? 7 : level)];
 }
+/* The entry also depends on the block size (round 6): the 20 / 24 KiB tables of levels 3-4 carry a chain ring of 2^11 / 2^12 positions,
+ * sized for 64 KiB blocks. In the reference's default 512 KiB blocks (and up to 2 MiB) a position's chain reaches 65 536 bytes back
+ * (ZXC_LZ_WINDOW_SIZE, src/lib/zxc_common.c:197-199): there levels 3-5 take the 80 KiB entry of levels 6-7 (ring 2^15) at their own search effort: on text 1.005 x the reference's size at 512 KiB blocks (2^11: 1.093 x, 2^12: 1.078 x, 2^14: 1.030 x). */
+static inline zxc_enc_level_t zxc_enc_level_bs(int level, uint32_t block_size) {
+    zxc_enc_level_t p = zxc_enc_level(level);
+    if (p.entry >= 2 && p.entry <= 4 && block_size > 65536u) p.entry = 5;
+    return p;
+}
 #endif

@@ -536,7 +536,7 @@ static int encode_launch(const void* d_src, uint64_t src_size, uint32_t block_si
         if (hipGetLastError() != hipSuccess) return ZXC_ERROR_GPU_UNAVAILABLE;  // (noticed here, not behind the encode launch)
         in = (const uint8_t*)d_work;
     }
-    zxc_enc_level_t lp = zxc_enc_level(level);
+    zxc_enc_level_t lp = zxc_enc_level_bs(level, block_size);
 #ifdef EXP_ENC_ENV  // (A/B builds only: search effort from the environment, "depth,sufficient,lazy")
     if (const char* e = getenv("ZXC_EXP_ENC")) { unsigned a, b2, c; if (sscanf(e, "%u,%u,%u", &a, &b2, &c) == 3) { lp.depth = a; lp.sufficient = b2; lp.lazy = c; } }
 #endif
