@@ -290,3 +290,32 @@ def test_push_streams_under_random_call_schedules(mockdev, ref):
         for lib_ in (mockdev, ref.lib):
             blob, dec, used = push_random_schedule(lib_, data, seekable_arc + b"trailing", random.Random(seed), bs, checksum)
             assert blob == want and dec == data and used == len(seekable_arc), (seed, lib_ is mockdev, len(blob), len(want), len(dec), used)
+
+
+def test_static_cctx_with_a_dictionary_keeps_its_lock(mockdev):
+    """zxc_compress_block on a static (caller-workspace) context checked the locked size against the effective
+    [dict | block] size and then stored the base size — the second identical call failed with ZXC_ERROR_BAD_BLOCK_SIZE (-14).
+    Reference: src/lib/zxc_dispatch.c:1653-1667."""
+    import ctypes as C
+    L = mockdev
+    L.zxc_static_cctx_workspace_size.restype = C.c_size_t
+    L.zxc_static_cctx_workspace_size.argtypes = [C.c_size_t, C.c_int]
+    L.zxc_init_static_cctx.restype = C.c_void_p
+    L.zxc_init_static_cctx.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.zxc_compress_block.restype = C.c_int64
+    L.zxc_compress_block.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    ws_size = L.zxc_static_cctx_workspace_size(65536, 3)
+    assert ws_size > 0
+    ws = C.create_string_buffer(ws_size + 64)
+    base = (C.addressof(ws) + 63) & ~63
+    init = api._CompressOpts(level=3, block_size=65536)
+    ctx = L.zxc_init_static_cctx(base, ws_size, C.byref(init))
+    assert ctx
+    rng = random.Random(3)
+    dict_ = _text(rng, 32768)
+    dbuf = C.create_string_buffer(dict_, len(dict_))
+    src = _text(rng, 3000)
+    o = api._CompressOpts(level=3, block_size=4096, dict=C.addressof(dbuf), dict_size=len(dict_))  # [32 KiB | 4 KiB] -> effective 64 KiB
+    dst = C.create_string_buffer(8192)
+    sizes = [L.zxc_compress_block(ctx, src, len(src), dst, len(dst), C.byref(o)) for _ in range(3)]
+    assert sizes[0] > 0 and sizes == [sizes[0]] * 3, sizes

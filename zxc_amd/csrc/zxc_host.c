@@ -783,6 +783,7 @@ typedef struct {
     int tail_err;         /* error to report after all queued blocks succeed */
     int saw_eof, done;
     uint32_t global_hash; /* rotl1-xor fold of the stored per-block checksums (zxc_internal.h:1390-1393) */
+    size_t stop_ip;       /* != 0: a piece ends in front of this position (the block-by-block walk over an irregular piece stops where the piece did) */
 } frame_walk_t;
 static int frame_source(void* ctx, uint32_t max_blocks, pipe_piece_t* p) {
     frame_walk_t* w = (frame_walk_t*)ctx;
@@ -792,6 +793,7 @@ static int frame_source(void* ctx, uint32_t max_blocks, pipe_piece_t* p) {
     const uint32_t hash0 = w->global_hash;
     while (!w->done && n < max_blocks) {
         if (w->ip >= w->src_size) { w->done = 1; break; }
+        if (w->stop_ip && w->ip >= w->stop_ip) break;
         const size_t rem = w->src_size - w->ip;
         uint8_t type;
         uint32_t csz;
@@ -878,7 +880,7 @@ static int frame_irregular_piece(frame_walk_t* w, frame_sink_t* k, const dict_re
         if ((size_t)st[i] > k->dst_capacity - k->total) { rc = ZXC_ERROR_DST_TOO_SMALL; break; }
         if ((uint32_t)st[i] > slot) { rc = ZXC_ERROR_CORRUPT_DATA; break; }
         rc = zxc_mi355x_memcpy_d2h(k->dst + k->total, (const uint8_t*)b.d_out + (size_t)i * slot, (size_t)st[i]);
-        k->total += (size_t)st[i];
+        if (rc == ZXC_OK) k->total += (size_t)st[i];
     }
     dev_bufs_free(&b);
     free(p.jobs);
@@ -941,10 +943,12 @@ int64_t zxc_decompress(const void* src_v, const size_t src_size, void* dst_v, co
         { const char* ev = getenv("ZXC_MI355X_FRAME_BATCH_MIB"); if (ev && atoi(ev) >= 1 && atoi(ev) <= 1024) nb = (uint32_t)(((size_t)atoi(ev) << 20) / block_size); }
         if (nb < 16u) nb = 16u;
         /* the piece had exactly this many blocks or fewer: walk block by block up to where it ended */
+        w.stop_ip = (size_t)k.irr[2];
         while (w.ip < (size_t)k.irr[2] && !w.done) {
             const int rc = frame_irregular_piece(&w, &k, &dr, nb);
             if (rc != ZXC_OK) return rc;
         }
+        w.stop_ip = 0;
         /* ... and go on behind it */
         if (w.done) break;
     }
@@ -1761,7 +1765,10 @@ int64_t zxc_compress_block(zxc_cctx* cctx, const void* src, const size_t src_siz
         if (level >= ZXC_LEVEL_DENSITY && !cctx->dense) return ZXC_ERROR_BAD_LEVEL;
     }
     cctx->level = level;
-    cctx->block_size = bs;
+    /* a static context keeps the size it was carved for (the lock above and zxc_compress_cctx's compare against it; the reference stores
+     * the EFFECTIVE size there, which for a locked context is that same value: src/lib/zxc_dispatch.c:1662-1667) — storing the base size
+     * made the second identical call with a dictionary fail with BAD_BLOCK_SIZE */
+    if (!cctx->in_workspace) cctx->block_size = bs;
     cctx->checksum = checksum_enabled;
     if (zxc_mi355x_device_count() <= 0) return ZXC_ERROR_GPU_UNAVAILABLE;
     if (!b_dict_size) { /* one piece of one block in the staging arena (no allocation on the device per call) */

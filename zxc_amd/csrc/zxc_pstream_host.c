@@ -463,7 +463,10 @@ static int ds_flush_slots(zxc_dstream* ds, uint32_t j0) {
     int32_t* st = (int32_t*)malloc((size_t)win * sizeof(int32_t));
     int rc = (jobs && st) ? ZXC_OK : ZXC_ERROR_MEMORY;
     const int verify = ds->want_verify && ds->file_ck;
-    while (rc == ZXC_OK && j0 < ds->n && !ds->tail_err) {
+    /* (a failure flag of its own: DS_BLOCK_HEADER may have set tail_err for a bad header BEHIND the collected batch, and what was
+     *  collected in front of it decodes first — a block that fails here wins over that header error, as in ds_sink: ADVICE r5) */
+    int block_err = 0;
+    while (rc == ZXC_OK && j0 < ds->n && !block_err) {
         uint32_t cnt;
         const uint8_t* h_comp;
         size_t comp_bytes;
@@ -488,7 +491,7 @@ static int ds_flush_slots(zxc_dstream* ds, uint32_t j0) {
         rc = run_jobs_on(h_comp, comp_bytes, jobs, cnt, (size_t)cnt * slot, bs, 0u, verify, st, &b, NULL, 0, NULL);
         if (rc != ZXC_OK) break;
         for (uint32_t j = 0; j < cnt && rc == ZXC_OK; j++) {
-            if (st[j] < 0) { ds->tail_err = st[j]; break; }
+            if (st[j] < 0) { block_err = st[j]; break; }
             if ((uint32_t)st[j] > slot) { rc = ZXC_ERROR_CORRUPT_DATA; break; } /* (a status is never trusted as a copy length) */
             rc = ps_host_reserve(&ds->decoded, &ds->decoded_cap, ds->decoded_size + (size_t)st[j], 1);
             if (rc == ZXC_OK) rc = zxc_mi355x_memcpy_d2h(ds->decoded + ds->decoded_size, (const uint8_t*)b.d_out + (size_t)j * slot, (size_t)st[j]);
@@ -497,6 +500,7 @@ static int ds_flush_slots(zxc_dstream* ds, uint32_t j0) {
         dev_bufs_free(&b);
         j0 += cnt;
     }
+    if (block_err) ds->tail_err = block_err;
     free(jobs);
     free(st);
     return rc;
