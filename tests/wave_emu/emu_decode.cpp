@@ -19,6 +19,11 @@ static size_t emu_rscratch_bytes = (size_t)4 << 20;  // scratch for the expanded
 extern "C" __attribute__((visibility("default"))) void emu_set_rscratch_bytes(size_t n) { emu_rscratch_bytes = n; }
 extern "C" __attribute__((visibility("default"))) uint32_t emu_last_section_count(int size_class) { return emu_last_secs[size_class]; }
 
+// per-block checksums: 1 = hashed by zxc_block_checksum_kernel beside the decode and merged into the statuses (the product's plan without
+// PRE blocks), 0 = inside the decode kernels (its plan with PRE blocks, dictionaries, the strict capacity)
+static int emu_ck_apart = 1;
+extern "C" __attribute__((visibility("default"))) void emu_set_ck_apart(int on) { emu_ck_apart = on; }
+
 // the strict per-block capacity of zxc_decompress_block_safe (the kernels' cap_override argument; 0 = block_size + 2112)
 static uint32_t emu_cap_override = 0;
 extern "C" __attribute__((visibility("default"))) void emu_set_cap_override(uint32_t cap) { emu_cap_override = cap; }
@@ -58,7 +63,10 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
         // the two-pass launch of zxc_hip_shim.hip, kernel by kernel: launch-order pass (histogram + scatter: order[], classes, work
         // lists), the section kernels of the three size classes, the lean kernel over every block, its second entry over the PRE
         // blocks, the full kernel over its list
-        const uint32_t tb = verify_trailer ? 4u : 0u, g256 = (n_jobs + 255u) / 256u;
+        const uint32_t tb0 = verify_trailer ? 4u : 0u, g256 = (n_jobs + 255u) / 256u;
+        const bool ck_apart = tb0 && emu_ck_apart;
+        const uint32_t tb = ck_apart ? tb0 | ZXC_DEV_TRAILER_ELSEWHERE : tb0;
+        std::vector<uint8_t> ck_bad(n_jobs + 16u, 0xEE);
         std::vector<uint32_t> hist(128, 0u), order(n_jobs), list(n_jobs + 2u, 0u), ctl(ZXC_DEV_CTL_WORDS, 0u), pre_entries(n_jobs);
         std::vector<zxc_dev_pre_t> pre(n_jobs);
         std::vector<zxc_dev_sec_t> secs(6u * (size_t)n_jobs);
@@ -72,7 +80,7 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
         };
         launch(g256, 256, [&] { zxc_order_hist_kernel(c.data() + 4096, jobs, n_jobs, block_size, hist.data()); });
         launch(g256, 256, [&] {
-            zxc_order_scatter_kernel(c.data() + 4096, jobs, n_jobs, block_size, hist.data(), order.data(), list.data(), tb, pre.data(), ctl.data(),
+            zxc_order_scatter_kernel(c.data() + 4096, jobs, n_jobs, block_size, hist.data(), order.data(), list.data(), tb0, pre.data(), ctl.data(),
                                      pre_entries.data(), secs.data(), (uint32_t)(emu_pscratch_bytes >> 4), emu_cap_override ? emu_cap_override : block_size + 2112u,
                                      (uint32_t)(emu_rscratch_bytes >> 4));
         });
@@ -99,9 +107,13 @@ int emu_decode_blocks(const uint8_t* comp, size_t comp_bytes, const zxc_dev_job_
         for (uint32_t b = 0; b < grid; b++) {
             memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));
             emu::run_wave([&] {
-                zxc_decode_blocks_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, verify_trailer ? 4u : 0u, scratch.data(),
+                zxc_decode_blocks_kernel(c.data() + 4096, jobs, n_jobs, o.data() + 4096, status, block_size, tb, scratch.data(),
                                          stride, 0u, busy.data(), n_slots, order.data(), emu_cap_override, list.data());
             }, b, grid, 64);
+        }
+        if (ck_apart) {
+            launch((n_jobs + 8u) / 9u, 64, [&] { zxc_block_checksum_kernel(c.data() + 4096, jobs, n_jobs, order.data(), ck_bad.data()); });
+            launch(g256, 256, [&] { zxc_checksum_merge_kernel(ck_bad.data(), status, n_jobs); });
         }
     }
     memcpy(out, o.data() + 4096, out_bytes);

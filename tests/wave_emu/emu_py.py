@@ -26,11 +26,12 @@ class Emu:
                                         C.c_void_p, C.c_uint32, C.c_int, C.c_char_p, C.c_uint32, C.c_char_p]
 
     def decode_jobs(self, comp: bytes, jobs: np.ndarray, out_bytes: int, block_size: int, verify_trailer=False,
-                    dict_=None, dict_huf=None, cap_override=0):
+                    dict_=None, dict_huf=None, cap_override=0, ck_apart=True):
         """Runs every job through one emulated wavefront. -> (status int32[n], output bytes).
         cap_override: the strict per-block capacity of zxc_decompress_block_safe (0: block_size + 2112)."""
         jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
         self.lib.emu_set_cap_override(int(cap_override))
+        self.lib.emu_set_ck_apart(int(ck_apart))  # (checksums by zxc_block_checksum_kernel beside the decode, or inside the decode kernels)
         out = C.create_string_buffer(max(out_bytes, 1))
         status = np.full(jobs.size, -999, dtype=np.int32)
         self.lib.emu_decode_blocks(comp, len(comp), jobs.ctypes.data, jobs.size, out, out_bytes, status.ctypes.data,

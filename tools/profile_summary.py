@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condense the rocprofv3 CSV outputs of tools/profile.sh (gpurun_out/<tag>_{kt,fetch,write,sq,tcp}) into
-profiles/<tag>_summary.json + <tag>_kernel_stats.csv, and enter the launch's HBM traffic into profiles/r5_traffic.json
+profiles/<tag>_summary.json + <tag>_kernel_stats.csv, and enter the launch's HBM traffic into profiles/r6_traffic.json
 (the table bench.py's roofline.traffic is read from) together with the content hash of the device sources that were profiled
 (bench.kernel_sources_hash(): bench.py reports the traffic only while that hash still matches its own tree).
 
@@ -121,19 +121,21 @@ if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
         algo = bench["roofline"]["algorithmic_bytes_per_launch"]
         out["hbm_traffic_bytes_per_launch"]["over_algorithmic"] = round((read + raw_w) / algo, 3)
         # the table bench.py reads
-        tp = os.path.join(P, "r5_traffic.json")
+        tp = os.path.join(P, "r6_traffic.json")
         tab = json.load(open(tp)) if os.path.exists(tp) else {}
         cfg = bench["config"]
         if what == "decode":
             lvl = int(bench["metric"].split("level ")[1].split(",")[0])
-            key, wl = f"decode_l{lvl}", {"tiles": cfg["prep"]["tiles"], "block_size": cfg["decoded_bytes_per_gpu"] // cfg["blocks_per_gpu"]}
+            bsz = 1 << (int(cfg["decoded_bytes_per_gpu"] // cfg["blocks_per_gpu"]) - 1).bit_length()  # (the last block of a tile may be short)
+            key, wl = f"decode_l{lvl}_bs{bsz}", {"tiles": cfg["prep"]["tiles"], "block_size": bsz}
         else:
             lvl = int(bench["metric"].split("level ")[1].split(",")[0])
-            key, wl = f"encode_l{lvl}", {"enc_mib": int(cfg["workload"].split(": ")[1].split(" MiB")[0])}
+            bsz = int(bench["metric"].split(" KiB blocks")[0].split(", ")[-1]) << 10
+            key, wl = f"encode_l{lvl}_bs{bsz}", {"enc_mib": int(cfg["workload"].split(": ")[1].split(" MiB")[0]), "block_size": bsz}
         sys.path.insert(0, ROOT)
         import bench as _bench
         tab[key] = {"workload": wl, "bytes_per_launch": int(read + raw_w), "read": int(read), "write": int(raw_w),
-                    "kernels": _bench.kernel_sources_hash(),
+                    "kernels": _bench.kernel_sources_hash(what),
                     "source": f"profiles/{tag}_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"}
         json.dump(tab, open(tp, "w"), indent=1)
 if "TCP_TCC_READ_REQ_sum" in pm:

@@ -1258,6 +1258,8 @@ __device__ __forceinline__ void decode_one_block(const uint8_t* __restrict__ com
     // the reference decodes frames and seekable ranges with block_size + ZXC_DECOMPRESS_TAIL_PAD; only the strict
     // Block API (zxc_decompress_block_safe, src/lib/zxc_dispatch.c:1815-1858) passes the caller's exact capacity
     const uint32_t cap = cap_override ? cap_override : block_size + 2112u;
+    const bool ck_here = !(trailer_bytes & ZXC_DEV_TRAILER_ELSEWHERE);  // (else zxc_block_checksum_kernel verifies, zxc_checksum_merge_kernel writes the verdicts)
+    trailer_bytes &= ~ZXC_DEV_TRAILER_ELSEWHERE;
     ScratchPool pool = {scratch, scratch_stride, slot_busy, n_slots, -1};
     const uint64_t comp_off = jobs[b].comp_off;
     const uint32_t src_sz = uni(jobs[b].comp_size);
@@ -1272,7 +1274,7 @@ __device__ __forceinline__ void decode_one_block(const uint8_t* __restrict__ com
         const uint32_t comp_sz = uni(ld32(src + 3));
         if ((uint64_t)8u + comp_sz + trailer_bytes > src_sz) {
             rc = E_SRC_TOO_SMALL;
-        } else if (trailer_bytes && wave_checksum32(src + 8, comp_sz, lane) != uni(ld32(src + 8 + comp_sz))) {
+        } else if (trailer_bytes && ck_here && wave_checksum32(src + 8, comp_sz, lane) != uni(ld32(src + 8 + comp_sz))) {
             rc = E_BAD_CHECKSUM;  // per-block checksum of the compressed payload (zxc_decompress.c:1662-1666)
         } else if (type == 1u || type == 2u) {
             rc = decode_lz_block<DICT>(src + 8, comp_sz, type == 2u, dst, out_len, cap, block_size, pool, L, lane, dbg, dict,
@@ -1450,6 +1452,8 @@ __device__ __forceinline__ void lean_one_block(const uint8_t* __restrict__ comp,
     // (cap_override: only ever 0 here. A launch with the strict capacity of zxc_decompress_block_safe — exact checks, none of
     // the reference's 4x-batch reserve — goes to the full kernel alone: zxc_hip_shim.hip. The argument stays for the ABI.)
     const uint32_t cap = cap_override ? cap_override : block_size + 2112u;
+    const bool ck_here = !(trailer_bytes & ZXC_DEV_TRAILER_ELSEWHERE);
+    trailer_bytes &= ~ZXC_DEV_TRAILER_ELSEWHERE;
 #ifdef EXP_TIMES  // experiment only (tools/blocktimes.py): status = start (hi 16) and duration (lo 16) in units of 32 ticks of the 100 MHz clock
     const uint64_t t_start = wall_clock64();
 #endif
@@ -1466,7 +1470,7 @@ __device__ __forceinline__ void lean_one_block(const uint8_t* __restrict__ comp,
         const uint32_t comp_sz = uni(ld32(src + 3));
         if ((uint64_t)8u + comp_sz + trailer_bytes > src_sz) {
             rc = E_SRC_TOO_SMALL;
-        } else if (trailer_bytes && wave_checksum32(src + 8, comp_sz, lane) != uni(ld32(src + 8 + comp_sz))) {
+        } else if (trailer_bytes && ck_here && wave_checksum32(src + 8, comp_sz, lane) != uni(ld32(src + 8 + comp_sz))) {
             rc = E_BAD_CHECKSUM;  // per-block checksum of the compressed payload (zxc_decompress.c:1662-1666)
         } else if (PRE) {  // (a GLO block, by classify_block: nothing else is compiled into the second entry)
             rc = type == 1u ? decode_lz_block_lean(src + 8, comp_sz, false, dst, out_len, cap, L, lane, pre + b, pscratch, false) : ZXC_DEV_E_INTERNAL;
@@ -1560,6 +1564,35 @@ zxc_decode_blocks_lean_pre_kernel(const uint8_t* __restrict__ comp, const zxc_de
     __shared__ LeanLds L;
     if (blockIdx.x >= uni(hdr[0])) return;
     lean_one_block<true>(comp, jobs, out, status, block_size, cap_override, trailer_bytes, uni(entries[blockIdx.x]), pre, pscratch, L, threadIdx.x, nullptr, 0);
+}
+
+// ------------------------------------------------------------------ per-block checksums beside the decode (round 6)
+// Nine blocks per wavefront (zxc_rapidhash.inc: group_checksum32), in launch order (neighbours are of similar weight). ck_bad[b] = 1 when
+// block b carries a checksum that does not match its payload — and only then: a block whose header the decode kernels refuse before they
+// would look at the checksum (too small, size beyond its bytes) keeps THEIR verdict (reference order: zxc_decompress.c:1655-1666).
+extern "C" __global__ void __launch_bounds__(64)
+zxc_block_checksum_kernel(const uint8_t* __restrict__ comp, const zxc_dev_job_t* __restrict__ jobs, uint32_t n_jobs,
+                          const uint32_t* __restrict__ order, uint8_t* __restrict__ ck_bad) {
+    const int lane = threadIdx.x;
+    const uint32_t slot = blockIdx.x * 9u + (uint32_t)lane / 7u;
+    const bool in = lane < 63 && slot < n_jobs;
+    const uint32_t b = in ? (order ? order[slot] : slot) : 0u;
+    const uint8_t* src = comp + jobs[b].comp_off;
+    const uint32_t src_sz = in ? jobs[b].comp_size : 0u;
+    uint32_t comp_sz = 0;
+    bool on = false;
+    if (src_sz >= 8u) {
+        comp_sz = ld32(src + 3);
+        on = (uint64_t)8u + comp_sz + 4u <= src_sz;
+    }
+    const uint32_t h = group_checksum32(src + 8, on ? comp_sz : 0u, lane, on);
+    if (on && lane % 7 == 0) ck_bad[b] = h != ld32(src + 8 + comp_sz) ? 1u : 0u;
+    else if (in && !on && lane % 7 == 0) ck_bad[b] = 0u;
+}
+extern "C" __global__ void __launch_bounds__(256)
+zxc_checksum_merge_kernel(const uint8_t* __restrict__ ck_bad, int32_t* __restrict__ status, uint32_t n_jobs) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n_jobs && ck_bad[i]) status[i] = E_BAD_CHECKSUM;
 }
 
 // ------------------------------------------------------------------ launch order

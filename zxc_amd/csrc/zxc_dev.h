@@ -34,6 +34,10 @@ typedef struct {          /* one coded section on a size class's work list */
     uint32_t pad[2];
 } zxc_dev_sec_t;
 /* Control words behind the launch-order buffer's order[] (zxc_hip_shim.hip): */
+/* trailer_bytes argument of the decode kernels: 4 = a per-block checksum trails every block; with this bit on top, the checksums are
+ * verified by zxc_block_checksum_kernel beside the decode (nine blocks per wavefront) and zxc_checksum_merge_kernel writes the verdicts:
+ * the decode kernels only account for the trailer's bytes (round 6) */
+#define ZXC_DEV_TRAILER_ELSEWHERE 0x80000000u
 #define ZXC_DEV_CTL_WORDS 32u
 #define ZXC_DEV_CTL_PRE 0u     /* [0] PRE blocks listed, [1] next to hand out (lean kernel, second entry) */
 #define ZXC_DEV_CTL_CURSOR 2u  /* scratch handed out so far, 16-byte units */

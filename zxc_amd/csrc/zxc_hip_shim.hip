@@ -68,6 +68,8 @@ ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l57)
 ZXC_ENCODE_DECL(zxc_encode_blocks_kernel_l67)
 extern "C" __global__ void zxc_prepend_dict_kernel(const uint8_t* src, uint64_t src_size, uint32_t block_size, const uint8_t* dict,
                                                    uint32_t dict_size, uint8_t* work, uint32_t n_blocks);
+extern "C" __global__ void zxc_block_checksum_kernel(const uint8_t* comp, const zxc_dev_job_t* jobs, uint32_t n_jobs, const uint32_t* order, uint8_t* ck_bad);
+extern "C" __global__ void zxc_checksum_merge_kernel(const uint8_t* ck_bad, int32_t* status, uint32_t n_jobs);
 extern "C" __global__ void zxc_block_offsets_kernel(uint32_t* sizes, uint64_t* offsets, uint32_t n_blocks, uint32_t max_size);
 extern "C" __global__ void zxc_gather_blocks_kernel(const uint8_t* slots, uint32_t slot_stride, const uint32_t* sizes,
                                                     const uint64_t* offsets, uint8_t* out, uint32_t n_blocks);
@@ -296,6 +298,7 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
     zxc_dev_pre_t* pre = NULL;
     uint8_t* pscratch = NULL;
     uint32_t pscratch_cap16 = 0;
+    uint8_t* ck_bad = NULL;    // per-block checksum verdicts of zxc_block_checksum_kernel (launches that verify, no PRE plan)
     uint8_t* rscratch = NULL;  // expanded literals of the blocks with RLE-coded literals that the lean kernel takes (LEAN_RLE)
     uint32_t rscratch_cap16 = 0;
     int k = -1;
@@ -315,7 +318,8 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
             // section records, 3 size classes x 2 n x 8 words | pre[n] x 4 words]
             const size_t ctl_at = 130u + 2u * (size_t)n_jobs, pre_ent_at = ctl_at + ZXC_DEV_CTL_WORDS;
             const size_t secs_at = (pre_ent_at + (size_t)n_jobs + 7u) & ~(size_t)7u, pre_at = secs_at + 48u * (size_t)n_jobs;
-            const size_t want = pre_at + 4u * (size_t)n_jobs;
+            const size_t ck_at = pre_at + 4u * (size_t)n_jobs;  // one byte per block: its checksum does not match (zxc_block_checksum_kernel)
+            const size_t want = ck_at + ((size_t)n_jobs + 3u) / 4u;
             if (o.cap < want) {
                 if (o.buf) (void)hipFree(o.buf);
                 o.buf = NULL;
@@ -392,6 +396,7 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
                     pre_entries = buf + pre_ent_at;
                     secs = (zxc_dev_sec_t*)(buf + secs_at);
                     pre = (zxc_dev_pre_t*)(buf + pre_at);
+                    ck_bad = (uint8_t*)(buf + ck_at);
                     if (pre_plan) {
                         pscratch = o.pscratch;
                         pscratch_cap16 = (uint32_t)(o.pscratch_cap >> 4);
@@ -429,8 +434,12 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
         // workgroups hold their stream for as long as the slowest one-wave block takes: VERDICT r3 weak #3)
         // Fixed grids pull work through counters.
         auto& o = g_dev[dev].ord[k];
-        const uint32_t cus = (uint32_t)g_dev[dev].cus, tb = verify_trailer ? 4u : 0u;
-        hipStream_t s0 = (hipStream_t)stream, s1 = s0, s2 = s0;
+        // Per-block checksums (round 6): in the plan without PRE blocks they are hashed by their own kernel, nine blocks per wavefront, on
+        // the second helper stream beside the decode; the decode kernels only skip the trailers, a last small kernel writes BAD_CHECKSUM
+        // over the status of the blocks that failed (inside the decode kernels 57 of 64 lanes idled through the hash: -10.5 % of the launch).
+        const bool ck_apart = verify_trailer && !pscratch_cap16 && ck_bad && o.aux2 && !getenv("ZXC_MI355X_CK_INLINE");
+        const uint32_t cus = (uint32_t)g_dev[dev].cus, tb = verify_trailer ? (ck_apart ? 4u | ZXC_DEV_TRAILER_ELSEWHERE : 4u) : 0u;
+        hipStream_t s0 = (hipStream_t)stream, s1 = s0, s2 = s0, s2b = NULL;
         bool forked = false;
         // A failure behind the fork must not leave kernels running on the helper streams against the caller's buffers
         // (the host path reuses or frees its arena right after an error): wait for them before reporting it.
@@ -476,14 +485,24 @@ static int decode_launch(const void* d_comp, const zxc_dev_job_t* d_jobs, uint32
                                (const uint32_t*)(ctl + ZXC_DEV_CTL_PRE), (const uint32_t*)pre_entries);
         } else {
             launch_full();
+            hipStream_t s3 = s0;  // the checksum kernel's stream
+            if (ck_apart) {
+                if (forked && hipStreamWaitEvent(o.aux2, o.fork, 0) == hipSuccess) s3 = o.aux2;
+                hipLaunchKernelGGL(zxc_block_checksum_kernel, dim3((n_jobs + 8u) / 9u), dim3(64), 0, s3, (const uint8_t*)d_comp, d_jobs, n_jobs,
+                                   (const uint32_t*)order, ck_bad);
+            }
             launch_rle(s0);
             hipLaunchKernelGGL(zxc_decode_blocks_lean_kernel, dim3(n_jobs), dim3(64), 0, s0, (const uint8_t*)d_comp, d_jobs, n_jobs,
                                (uint8_t*)d_out, d_status, block_size, order, cap_override, tb, (const zxc_dev_pre_t*)pre, rscratch);
+            if (s3 != s0) { s2b = s3; }
         }
         if (forked) {
             if (hipEventRecord(o.join, s1) != hipSuccess || hipStreamWaitEvent(s0, o.join, 0) != hipSuccess) return fail();
             if (s2 != s1 && (hipEventRecord(o.join2, s2) != hipSuccess || hipStreamWaitEvent(s0, o.join2, 0) != hipSuccess)) return fail();
+            if (s2b && (hipEventRecord(o.join2, s2b) != hipSuccess || hipStreamWaitEvent(s0, o.join2, 0) != hipSuccess)) return fail();
         }
+        if (ck_apart)  // behind every kernel that writes a status
+            hipLaunchKernelGGL(zxc_checksum_merge_kernel, dim3((n_jobs + 255u) / 256u), dim3(256), 0, s0, (const uint8_t*)ck_bad, d_status, n_jobs);
     } else
         hipLaunchKernelGGL(zxc_decode_blocks_kernel, dim3(n_jobs), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)d_comp,
                            d_jobs, n_jobs, (uint8_t*)d_out, d_status, block_size, verify_trailer ? 4u : 0u,
