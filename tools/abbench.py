@@ -10,21 +10,22 @@ TMP = "/tmp/zxc_abbench"
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
     import numpy as np, torch, zxc_amd
     level = int(os.environ.get("AB_LEVEL", "3"))
+    BS = int(os.environ.get("AB_BLOCK_SIZE", "65536"))  # (the corpus re-encoded by the reference at this block size)
     dev = torch.device("cuda", 0)
     comp = np.load(f"{TMP}/comp.npy"); sizes = np.load(f"{TMP}/sizes.npy"); want = np.load(f"{TMP}/want.npy")
     n = min(sizes.size, int(os.environ.get("AB_MAXBLOCKS", "1000000000")))  # (AB_MAXBLOCKS: the first blocks only)
-    sizes = sizes[:n]; want = want[:n * 65536]
+    sizes = sizes[:n]; want = want[:n * BS]
     jobs = np.zeros(n, dtype=zxc_amd.api.JOB_DTYPE)
     jobs["comp_size"] = sizes
     jobs["comp_off"] = np.concatenate([[0], np.cumsum(sizes.astype(np.uint64))[:-1]])
-    jobs["out_off"] = np.arange(n, dtype=np.uint64) * 65536
-    jobs["out_len"] = 65536
+    jobs["out_off"] = np.arange(n, dtype=np.uint64) * BS
+    jobs["out_len"] = BS
     d_comp = torch.from_numpy(comp).to(dev); d_want = torch.from_numpy(want).to(dev)
     d_jobs = torch.frombuffer(bytearray(jobs.tobytes()), dtype=torch.uint8).to(dev)
-    d_out = torch.zeros(n * 65536 + 256, dtype=torch.uint8, device=dev)
+    d_out = torch.zeros(n * BS + 256, dtype=torch.uint8, device=dev)
     d_st = torch.zeros(n, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    def step(): zxc_amd.decode_blocks_device(d_comp.data_ptr(), d_jobs.data_ptr(), n, d_out.data_ptr(), d_st.data_ptr(), 65536, False, stream)
+    def step(): zxc_amd.decode_blocks_device(d_comp.data_ptr(), d_jobs.data_ptr(), n, d_out.data_ptr(), d_st.data_ptr(), BS, False, stream)
     step(); step(); torch.cuda.synchronize()
     if os.environ.get("AB_PIVPROF"):  # library built with -DEXP_PIV_PROF: clock split of the PivCo section decoder in output bytes 64..127
         pr = d_out[:n * 65536].view(-1, 65536)[:, 64:128].cpu().numpy().view(np.uint32).astype(np.float64)
@@ -73,9 +74,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         res = [(np.minimum(end, edges[i+1]) - np.maximum(start, edges[i])).clip(0).sum() / (edges[i+1]-edges[i]) for i in range(bins)]
         print("residency per time bin:", " ".join(f"{r:.0f}" for r in res))
         worst = np.argsort(-dur)[:12]
-        print("slowest blocks (index in corpus tile, us, compressed size):", [(int(i % 3234), int(dur[i]), int(sizes[i])) for i in worst], flush=True)
+        print("slowest blocks (index, us, compressed size):", [(int(i), int(dur[i]), int(sizes[i])) for i in worst])
+        slots = 256 * 24
+        print(f"sum of block times / {slots} wavefront slots = {dur.sum() / slots:.0f} us; longest block {dur.max():.0f} us; launch span {end.max():.0f} us "
+              f"({'fewer blocks than slots: the launch lasts as long as its longest block' if st.size <= slots else 'rounds of wavefronts'})", flush=True)
         sys.exit(0)
-    ok = bool((d_st == 65536).all().item()) and torch.equal(d_out[:n * 65536], d_want)
+    ok = bool((d_st == BS).all().item()) and torch.equal(d_out[:n * BS], d_want)
     best = 1e9
     for _ in range(3):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -83,8 +87,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         for _ in range(5): step()
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 5)
-    ok = ok and torch.equal(d_out[:n * 65536], d_want)
-    print(f"{os.environ.get('ZXC_LIB_VARIANT','libzxc_mi355x.so'):28s} L{level} blocks {n} ok={ok} {best:7.3f} ms {n*65536/best/1e6:8.1f} GB/s", flush=True)
+    ok = ok and torch.equal(d_out[:n * BS], d_want)
+    print(f"{os.environ.get('ZXC_LIB_VARIANT','libzxc_mi355x.so'):28s} L{level} blocks {n} ok={ok} {best:7.3f} ms {n*BS/best/1e6:8.1f} GB/s", flush=True)
 elif __name__ == "__main__":
     import multiprocessing as mp
     import numpy as np, torch, bench
@@ -92,7 +96,8 @@ elif __name__ == "__main__":
     tiles = int(os.environ.get("AB_TILES", "3")); level = int(os.environ.get("AB_LEVEL", "3"))
     os.makedirs(TMP, exist_ok=True)
     with mp.get_context("spawn").Pool(min(32, os.cpu_count() or 1)) as pool:
-        d_comp, sizes, d_want, *_ = bench.build_rank_corpus(0, tiles * corpus.TILE_BLOCKS, level, 65536, pool, torch.device("cpu"))
+        BS = int(os.environ.get("AB_BLOCK_SIZE", "65536"))
+        d_comp, sizes, d_want, *_ = bench.build_rank_corpus(0, tiles * (corpus.TILE_BYTES // BS), level, BS, pool, torch.device("cpu"))
     np.save(f"{TMP}/comp.npy", d_comp.numpy()); np.save(f"{TMP}/sizes.npy", sizes); np.save(f"{TMP}/want.npy", d_want.numpy())
     for lib in sys.argv[1:]:
         env = dict(os.environ); env["ZXC_LIB_VARIANT"] = lib; env["ZXC_TOOLS_AB"] = "1"
